@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- body*substeps/s of the XPBD stepper hot path on N MI355X GPUs of one node.
+
+A "step" is one frame: xpbd_world_step(dt = 1/60, substeps) over the rank's resident
+bodies, i.e. for every body `solver::step(body, shape, dt, substeps)` (reference
+src/solver.rs:3-17).  Workload at N = 1: BASELINE.json's metric configuration, 262 144
+rigid bodies (unit boxes) x 20 substeps/frame, bodies already resident in HBM (SoA).
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL, used only for the
+barrier and the MAX-over-ranks of the wall time).  Bodies never interact in the
+reference, so the world is sharded by contiguous body-index range with NO data-path
+collective; scaling is weak (every rank steps --bodies bodies).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_step) at the
+algorithmic 412 B per body per launch against the 8 TB/s HBM peak;
+`cpu_baseline` times the CPU oracle (C restatement of the reference, single thread like
+the reference) on a bounded sample of the same bodies on this node's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FRAME_TIME = 1.0 / 60.0  # reference src/app.rs:15
+
+
+def reduce_max_seconds(seconds):
+    """MAX over ranks of a wall time (identity when torch.distributed is not initialised)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def cpu_baseline(state, shape_id, verts, offsets, substeps, budget_s=12.0, sample=8192):
+    """Times the CPU oracle on the first `sample` bodies of the GPU's current state."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    n = min(sample, state.shape[0])
+    bodies, sid = state[:n].copy(), shape_id[:n].copy()
+    t0 = time.perf_counter()
+    bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps)   # calibration frame (also timed)
+    one = time.perf_counter() - t0
+    frames = int(max(2, min(400, budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps)
+    sec = time.perf_counter() - t0
+    out = {"value": n * substeps * frames / sec, "unit": "body*substeps/s", "cores": 1, "kind": "port",
+           "sample": "first %d bodies of the benchmark state after warmup, %d frames x %d substeps, %.1f s, "
+                     "oracle/xpbd_oracle.c (C restatement of the reference, gcc -O2 -ffp-contract=off), 1 thread "
+                     "like the single-threaded reference" % (n, frames, substeps, sec)}
+    # all host cores, for information (the reference itself is single-threaded)
+    cores = len(os.sched_getaffinity(0))
+    if cores > 1:
+        f2 = max(2, frames // 2)
+        t0 = time.perf_counter()
+        for _ in range(f2):
+            bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps, threads=cores)
+        out["value_all_cores"] = n * substeps * f2 / (time.perf_counter() - t0)
+        out["cores_all"] = cores
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--bodies", type=int, default=262144, help="bodies per GPU (weak scaling)")
+    ap.add_argument("--substeps", type=int, default=20)
+    ap.add_argument("--scene", default="boxes-drop", choices=["boxes", "mixed", "boxes-drop", "mixed-drop"])
+    ap.add_argument("--mode", default="fused", choices=["fused", "substep"])
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--block-size", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world_size, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
+
+    from constraint_solver_amd import capi
+    from constraint_solver_amd.sharding import shard_range
+
+    kind = {"boxes": capi.SCENE_BOXES, "mixed": capi.SCENE_MIXED, "boxes-drop": capi.SCENE_BOXES_DROP,
+            "mixed-drop": capi.SCENE_MIXED_DROP}[args.scene]
+    mode = capi.MODE_FUSED if args.mode == "fused" else capi.MODE_PER_SUBSTEP
+    total = args.bodies * world_size
+    first, count = shard_range(total, rank, world_size)
+    verts, offsets = capi.scene_shapes(kind)
+    bodies, shape_id = capi.scene_generate(kind, args.seed, total, first=first, count=count)
+
+    world = capi.World(device=local_rank, mode=mode, block_size=args.block_size)
+    world.set_shapes(verts, offsets)
+    world.upload(bodies, shape_id)                       # inputs resident in HBM before any timing
+    stream = torch.cuda.current_stream()
+    world.set_stream(stream.cuda_stream)                 # so torch.cuda.Event brackets OUR launches
+
+    for _ in range(args.warmup):
+        world.step(FRAME_TIME, args.substeps)
+    torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        world.step(FRAME_TIME, args.substeps)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    wall = reduce_max_seconds(wall)
+    device_ms = ev0.elapsed_time(ev1)                    # HIP events on the kernels' stream
+
+    result = None
+    if rank == 0:
+        launches_per_step = 1 if mode == capi.MODE_FUSED else args.substeps
+        launch_s = device_ms * 1e-3 / (args.steps * launches_per_step)
+        bytes_per_launch = capi.BYTES_PER_BODY_SUBSTEP * count   # 412 B x bodies, fused or not
+        achieved = bytes_per_launch / launch_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            key = "%s_%d" % (args.mode, count)
+            traffic = json.load(open(tfile)).get(key, {}).get("bytes_per_launch")
+        result = {
+            "metric": "body*substeps/sec at 262k rigid bodies, 20 substeps/frame",
+            "value": total * args.substeps * args.steps / wall,
+            "unit": "body*substeps/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d %s per GPU x %d substeps/frame, dt=1/60, ground contacts "
+                                   "(reference semantics), seeded scene '%s'"
+                                   % (args.bodies, "unit boxes" if "boxes" in args.scene else "mixed convex polyhedra",
+                                      args.substeps, args.scene),
+                       "bodies_per_gpu": args.bodies, "bodies_total": total, "substeps": args.substeps,
+                       "mode": args.mode, "sharding": "contiguous body-index ranges, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_step", "launch_us": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
+                         "note": ("fused: all %d substeps of a body run in registers, so one launch moves 412 B/body "
+                                  "once and the kernel is f64-VALU bound, not HBM bound" % args.substeps)
+                         if mode == capi.MODE_FUSED else "one launch per substep: state round-trips HBM every substep"},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            state = world.download()
+            result["cpu_baseline"] = cpu_baseline(state, shape_id, verts, offsets, args.substeps)
+        print(json.dumps(result), flush=True)
+    barrier()
+    world.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

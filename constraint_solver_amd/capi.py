@@ -1,0 +1,289 @@
+"""ctypes binding of the C ABI (include/xpbd.h) and of the host mirror's C window.
+
+Test / bench glue only: the product is the shared library.  There is no Python or
+CPU fallback -- if libxpbd_hip.so is missing the import fails, and without a GPU
+every compute call returns an error that is raised as XpbdError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_PKG, "lib")
+
+RIGID_DOUBLES = 38
+BYTES_PER_BODY_SUBSTEP = 412  # read 13+25 doubles + 4 B shape id, write 13 doubles
+
+MODE_FUSED = 0
+MODE_PER_SUBSTEP = 1
+FLAG_TRACE_CONTACTS = 1
+
+OK, E_INVALID, E_HIP, E_OOM, E_SINGULAR_INERTIA, E_NO_DEVICE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+
+# xpbd_rigid field -> (first double, count); order of reference src/rigid.rs:6-50
+RIGID_FIELDS = {
+    "inverse_mass": (0, 1), "inverse_inertia": (1, 9), "external_force": (10, 3), "internal_force": (13, 3),
+    "external_torque": (16, 3), "internal_torque": (19, 3), "velocity": (22, 3), "angular_velocity": (25, 3),
+    "center_of_mass": (28, 3), "position": (31, 3), "rotation": (34, 4),
+}
+
+# Every symbol include/xpbd.h declares (tests check the library exports all of them).
+ABI_SYMBOLS = [
+    "xpbd_abi_version", "xpbd_last_error", "xpbd_config_default", "xpbd_device_count", "xpbd_world_create",
+    "xpbd_world_destroy", "xpbd_world_set_shapes", "xpbd_world_upload_bodies", "xpbd_world_download_bodies",
+    "xpbd_world_body_count", "xpbd_world_step", "xpbd_world_synchronize", "xpbd_world_download_contacts",
+    "xpbd_world_download_contact_masks", "xpbd_world_set_stream", "xpbd_world_get_stream", "xpbd_world_set_mode",
+    "xpbd_step_one", "xpbd_selftest_div_sqrt",
+]
+
+
+class XpbdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("xpbd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("mode", C.c_uint32), ("flags", C.c_uint32),
+                ("block_size", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+_u32p = C.POINTER(C.c_uint32)
+_f64p = C.POINTER(C.c_double)
+
+
+def _load(name):
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(no CPU fallback exists)" % path)
+    return C.CDLL(path)
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """libxpbd_hip.so with argtypes set.  Loading works without a GPU; compute calls then fail loudly."""
+    global _hip
+    if _hip is None:
+        L = _load("libxpbd_hip.so")
+        L.xpbd_abi_version.restype = C.c_uint32
+        L.xpbd_last_error.restype = C.c_char_p
+        L.xpbd_config_default.argtypes = [C.POINTER(Config)]
+        L.xpbd_config_default.restype = None
+        L.xpbd_world_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Config)]
+        L.xpbd_world_destroy.argtypes = [C.c_void_p]
+        L.xpbd_world_destroy.restype = None
+        L.xpbd_world_set_shapes.argtypes = [C.c_void_p, _f64p, _u32p, C.c_uint32]
+        L.xpbd_world_upload_bodies.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.c_uint32]
+        L.xpbd_world_download_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.xpbd_world_body_count.argtypes = [C.c_void_p]
+        L.xpbd_world_body_count.restype = C.c_uint32
+        L.xpbd_world_step.argtypes = [C.c_void_p, C.c_double, C.c_uint32]
+        L.xpbd_world_synchronize.argtypes = [C.c_void_p]
+        L.xpbd_world_download_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, _u32p]
+        L.xpbd_world_download_contact_masks.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_uint32]
+        L.xpbd_world_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.xpbd_world_get_stream.argtypes = [C.c_void_p]
+        L.xpbd_world_get_stream.restype = C.c_void_p
+        L.xpbd_world_set_mode.argtypes = [C.c_void_p, C.c_uint32]
+        L.xpbd_step_one.argtypes = [C.c_void_p, _f64p, C.c_uint32, C.c_double, C.c_uint32]
+        L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()  # libxpbd_host.so links against it
+        L = _load("libxpbd_host.so")
+        L.xpbdh_scene_shapes.argtypes = [C.c_uint32, _f64p, C.c_uint32, _u32p, C.c_uint32]
+        L.xpbdh_scene_generate.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, _u32p]
+        L.xpbdh_default_grid_width.argtypes = [C.c_uint32]
+        L.xpbdh_default_grid_width.restype = C.c_uint32
+        L.xpbdh_rigid_metrics.argtypes = [C.c_uint32, C.c_double, C.c_double, _f64p]
+        L.xpbdh_rigid_metrics.restype = None
+        L.xpbdh_rigid_new.argtypes = [_f64p, C.c_void_p]
+        L.xpbdh_rigid_frame.argtypes = [C.c_void_p, _f64p]
+        L.xpbdh_rigid_frame.restype = None
+        L.xpbdh_world_new.argtypes = [C.c_void_p, C.c_void_p]
+        L.xpbdh_shape_plane.argtypes = [C.c_uint32, C.c_double, C.c_uint32, _f64p]
+        _host = L
+    return _host
+
+
+def _check(rc):
+    if rc != OK:
+        raise XpbdError(rc, hip_lib().xpbd_last_error().decode())
+
+
+def _f64(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def _u32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+class World:
+    """N-body world on one GPU: thin wrapper over xpbd_world_* (reference World::integrate, src/world.rs:34-43)."""
+
+    def __init__(self, device=0, mode=MODE_FUSED, trace_contacts=False, block_size=0):
+        L = hip_lib()
+        cfg = Config()
+        L.xpbd_config_default(C.byref(cfg))
+        cfg.device, cfg.mode, cfg.block_size = device, mode, block_size
+        cfg.flags = FLAG_TRACE_CONTACTS if trace_contacts else 0
+        self._h = C.c_void_p()
+        _check(L.xpbd_world_create(C.byref(self._h), C.byref(cfg)))
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            hip_lib().xpbd_world_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_shapes(self, verts_xyz, vert_offsets):
+        v = np.ascontiguousarray(verts_xyz, dtype=np.float64).reshape(-1)
+        o = np.ascontiguousarray(vert_offsets, dtype=np.uint32)
+        if v.size == 0:
+            v = np.zeros(3)
+        _check(hip_lib().xpbd_world_set_shapes(self._h, _f64(v), _u32(o), o.size - 1))
+
+    def upload(self, bodies, shape_id=None):
+        b = np.ascontiguousarray(bodies, dtype=np.float64).reshape(-1, RIGID_DOUBLES)
+        sid = None if shape_id is None else np.ascontiguousarray(shape_id, dtype=np.uint32)
+        _check(hip_lib().xpbd_world_upload_bodies(self._h, b.ctypes.data, None if sid is None else _u32(sid), b.shape[0]))
+        self.n = b.shape[0]
+
+    def step(self, dt, substeps):
+        _check(hip_lib().xpbd_world_step(self._h, dt, substeps))
+
+    def synchronize(self):
+        _check(hip_lib().xpbd_world_synchronize(self._h))
+
+    def download(self):
+        out = np.empty((self.n, RIGID_DOUBLES), dtype=np.float64)
+        _check(hip_lib().xpbd_world_download_bodies(self._h, out.ctypes.data, self.n))
+        return out
+
+    def contacts(self):
+        """(k, 2) uint32 array of (body, vertex) of the last substep, reference push order."""
+        n = C.c_uint32(0)
+        rc = hip_lib().xpbd_world_download_contacts(self._h, None, 0, C.byref(n))
+        if rc not in (OK, E_CAPACITY):
+            _check(rc)
+        out = np.empty((n.value, 2), dtype=np.uint32)
+        if n.value:
+            _check(hip_lib().xpbd_world_download_contacts(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def contact_masks(self, substeps):
+        out = np.empty((substeps, self.n), dtype=np.uint32)
+        _check(hip_lib().xpbd_world_download_contact_masks(self._h, _u32(out), substeps, self.n))
+        return out
+
+    def set_stream(self, stream_ptr):
+        _check(hip_lib().xpbd_world_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_mode(self, mode):
+        _check(hip_lib().xpbd_world_set_mode(self._h, mode))
+
+
+def step_one(rigid, verts_xyz, dt, substeps):
+    """solver::step for one body (src/solver.rs:3) through xpbd_step_one; returns the new 38-double state."""
+    r = np.array(rigid, dtype=np.float64).reshape(RIGID_DOUBLES).copy()
+    v = np.ascontiguousarray(verts_xyz, dtype=np.float64).reshape(-1)
+    _check(hip_lib().xpbd_step_one(r.ctypes.data, _f64(v), v.size // 3, dt, substeps))
+    return r
+
+
+def selftest_div_sqrt(a, b, device=0):
+    """(a / b, sqrt(a)) computed on the GPU with the kernels' own compile flags."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    q, s = np.empty_like(a), np.empty_like(a)
+    _check(hip_lib().xpbd_selftest_div_sqrt(device, _f64(a), _f64(b), _f64(q), _f64(s), a.size))
+    return q, s
+
+
+# ---- host mirror (CPU set-up math; no GPU needed) -------------------------------
+SCENE_BOXES, SCENE_MIXED, SCENE_BOXES_DROP, SCENE_MIXED_DROP = 0, 1, 2, 3
+SHAPE_CUBE, SHAPE_TETRAHEDRON, SHAPE_ICOSAHEDRON = 0, 1, 2
+
+
+def scene_shapes(kind):
+    verts = np.zeros(3 * 64)
+    off = np.zeros(9, dtype=np.uint32)
+    ns = host_lib().xpbdh_scene_shapes(kind, _f64(verts), 64, _u32(off), 8)
+    if ns < 0:
+        raise XpbdError(E_CAPACITY, "scene shape tables too large")
+    off = off[: ns + 1].copy()
+    return verts[: 3 * off[-1]].reshape(-1, 3).copy(), off
+
+
+def default_grid_width(n):
+    return int(host_lib().xpbdh_default_grid_width(n))
+
+
+def scene_generate(kind, seed, n, first=0, count=None, grid_w=None):
+    """Bodies [first, first+count) of the n-body seeded scene: ((count,38) f64, (count,) u32)."""
+    count = n - first if count is None else count
+    grid_w = default_grid_width(n) if grid_w is None else grid_w
+    bodies = np.zeros((count, RIGID_DOUBLES))
+    sid = np.zeros(count, dtype=np.uint32)
+    rc = host_lib().xpbdh_scene_generate(kind, seed, grid_w, first, count, bodies.ctypes.data, _u32(sid))
+    if rc != OK:
+        raise XpbdError(rc, "scene generation failed")
+    return bodies, sid
+
+
+def rigid_metrics(shape, scale, density):
+    out = np.zeros(14)
+    host_lib().xpbdh_rigid_metrics(shape, scale, density, _f64(out))
+    return out
+
+
+def rigid_new(metrics):
+    out = np.zeros(RIGID_DOUBLES)
+    m = np.ascontiguousarray(metrics, dtype=np.float64)
+    rc = host_lib().xpbdh_rigid_new(_f64(m), out.ctypes.data)
+    if rc != OK:
+        raise XpbdError(rc, "Inertia tensor is not invertible")
+    return out
+
+
+def rigid_frame(rigid):
+    r = np.ascontiguousarray(rigid, dtype=np.float64)
+    out = np.zeros(7)
+    host_lib().xpbdh_rigid_frame(r.ctypes.data, _f64(out))
+    return out
+
+
+def world_new():
+    a, b = np.zeros(RIGID_DOUBLES), np.zeros(RIGID_DOUBLES)
+    rc = host_lib().xpbdh_world_new(a.ctypes.data, b.ctypes.data)
+    if rc != OK:
+        raise XpbdError(rc, "World::new failed")
+    return a, b
+
+
+def shape_planes(shape, scale=1.0):
+    out = np.zeros(4)
+    n = host_lib().xpbdh_shape_plane(shape, scale, 0xFFFFFFFF, _f64(out))
+    planes = np.zeros((n, 4))
+    for i in range(n):
+        host_lib().xpbdh_shape_plane(shape, scale, i, _f64(planes[i]))
+    return planes

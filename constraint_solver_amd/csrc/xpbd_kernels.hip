@@ -1,0 +1,422 @@
+// xpbd_kernels.hip -- gfx950 (MI355X, CDNA4, wave64) kernels of the XPBD stepper.
+//
+// Hot path rebuilt here (reference file:line):
+//   solver::step substep loop        src/solver.rs:6-16
+//   Rigid::frame                     src/rigid.rs:75-80
+//   Rigid::integrate                 src/rigid.rs:82-99
+//   collision::ground                src/collision.rs:13-35   (+ Frame ops src/frame.rs:30-53)
+//   solver::solve                    src/solver.rs:19-27
+//   Constraint::{current_distance, inverse_resitance, act}    src/constraint.rs:21-37
+//   Rigid::apply_impulse             src/rigid.rs:113-123
+//   Rigid::derive                    src/rigid.rs:101-109
+//
+// Mapping: one lane = one body, all arithmetic IEEE f64 in the reference's
+// operation order (compile with -ffp-contract=off).  No MFMA: this is 3-vector
+// math, not a contraction.  State lives in registers across substeps; shape
+// vertex tables sit in LDS; every global access is a contiguous 512-byte wave
+// access on the SoA arrays (xpbd_kernels.h).
+#include "xpbd_kernels.h"
+#include "xpbd_math.hpp"
+
+namespace xpbd {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Per-body state held in registers.
+// ---------------------------------------------------------------------------
+struct BodyStatic {
+    double inv_mass;
+    Mat3 inv_inertia;
+    Vec3 ext_force, int_force, ext_torque, int_torque;
+    Vec3 com;
+};
+
+struct BodyDynamic {
+    Vec3 pos;
+    Quat rot;
+    Vec3 vel;
+    Vec3 ang;
+};
+
+__device__ __forceinline__ Vec3 load3(const double *base, uint32_t field, uint32_t stride, uint32_t i)
+{
+    return Vec3{base[(size_t)(field + 0) * stride + i], base[(size_t)(field + 1) * stride + i],
+                base[(size_t)(field + 2) * stride + i]};
+}
+
+__device__ __forceinline__ void store3(double *base, uint32_t field, uint32_t stride, uint32_t i, Vec3 v)
+{
+    base[(size_t)(field + 0) * stride + i] = v.x;
+    base[(size_t)(field + 1) * stride + i] = v.y;
+    base[(size_t)(field + 2) * stride + i] = v.z;
+}
+
+// Rigid::frame().position  (src/rigid.rs:77): (position + com) + rotation * (-com)
+__device__ __forceinline__ Vec3 frame_origin(Vec3 pos, Quat rot, Vec3 com)
+{
+    return (pos + com) + rot * (-com);
+}
+
+// One substep of solver::step for one body.  Returns the ground-contact mask
+// (bit v set <=> shape vertex v produced a constraint, src/collision.rs:18).
+//
+// ground() only reads the post-integrate pose and the past frame, and solve()
+// consumes the constraints in push order, so the two reference loops are run
+// as one: constraint v is built from the frozen post-integrate frame `cur`
+// and immediately projected onto the live pose (pos, rot).  The arithmetic and
+// its order per constraint are exactly the reference's.
+__device__ __forceinline__ uint32_t substep(BodyDynamic &d, const BodyStatic &s, double h, double compliance,
+                                            const double *verts, uint32_t n_verts)
+{
+    // src/solver.rs:7-9
+    const Vec3 past_pos = d.pos;
+    const Quat past_rot = d.rot;
+    const Frame past{frame_origin(d.pos, d.rot, s.com), d.rot};
+
+    // Rigid::integrate, src/rigid.rs:82-99
+    {
+        const Vec3 force = s.ext_force + d.rot * s.int_force;
+        d.vel = d.vel + (h * force) * s.inv_mass;
+        d.pos = d.pos + h * d.vel;
+
+        const Vec3 torque = s.ext_torque + d.rot * s.int_torque;
+        d.ang = d.ang + (h * s.inv_inertia) * torque;
+        const Quat dq = ((h * 0.5) * Quat{0.0, d.ang.x, d.ang.y, d.ang.z}) * d.rot;
+        d.rot = normalized(d.rot + dq);
+    }
+
+    // Frame of the integrated body, frozen for the whole of ground() (src/collision.rs:17,24),
+    // and its inverse (src/frame.rs:30-37), shared by every penetrating vertex.
+    const Frame cur{frame_origin(d.pos, d.rot, s.com), d.rot};
+    const Frame cur_inv = inverse(cur);
+
+    uint32_t mask = 0;
+    for (uint32_t v = 0; v < n_verts; ++v) {
+        const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
+        const Vec3 x = cur * vertex;          // src/collision.rs:17
+        if (x.z >= 0.0)                       // src/collision.rs:18
+            continue;
+        mask |= 1u << v;
+
+        // src/collision.rs:22-29
+        const Vec3 target{x.x, x.y, 0.0};
+        const Vec3 correction = target - x;
+        const Vec3 local = cur_inv * x;               // src/frame.rs:41
+        const Vec3 delta = x - past * local;          // src/frame.rs:42-43
+        const Vec3 delta_tangential = delta - project_on(delta, correction);
+        const Vec3 c0 = x;
+        const Vec3 c1 = target - 1.0 * delta_tangential;
+
+        // solver::solve body, src/solver.rs:23-25 (distance == 0.0, src/collision.rs:30)
+        const Vec3 difference = c1 - c0;                       // src/constraint.rs:13-15
+        const double current_distance = length(difference);    // src/constraint.rs:21-23
+        const Vec3 direction = difference * (1.0 / current_distance); // src/constraint.rs:17-19
+        // inverse_resitance, src/constraint.rs:25-32 (reads the LIVE pose)
+        const Vec3 angular_impulse = conjugate(d.rot) * cross(c0 - (d.pos + s.com), direction);
+        const double w = s.inv_mass + dot(s.inv_inertia * angular_impulse, angular_impulse);
+        const double lagrange = (current_distance - 0.0) / (w + compliance);
+        // act -> apply_impulse, src/constraint.rs:34-37, src/rigid.rs:113-123
+        const Vec3 impulse = lagrange * direction;
+        d.pos = d.pos + impulse * s.inv_mass;
+        const Vec3 arm = c0 - (d.pos + s.com);
+        const Quat spin = quat_sv(0.0, cross(s.inv_inertia * arm, impulse));
+        d.rot = d.rot + (0.5 * spin) * d.rot;
+        d.rot = normalized(d.rot);
+    }
+
+    // Rigid::derive, src/rigid.rs:101-109
+    d.vel = (d.pos - past_pos) / h;
+    Quat dr = d.rot * conjugate(past_rot);
+    if (dr.s < 0.0)
+        dr = -dr;
+    d.ang = (2.0 * vec_of(dr)) / h;
+    return mask;
+}
+
+// ---------------------------------------------------------------------------
+// k_step: `substeps` substeps for every body in one launch.
+// LDS: the shape vertex tables (<= a few hundred bytes), staged once per block.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kMaxStepBlock = 256;
+
+template <bool TRACE>
+__global__ void __launch_bounds__(kMaxStepBlock) k_step(BodyArrays b, ShapeTable shapes, double h, uint32_t substeps,
+                       uint32_t *__restrict__ last_mask, uint32_t *__restrict__ trace_masks,
+                       uint32_t trace_row0)
+{
+    extern __shared__ double lds[]; // [total_verts*3] doubles, then [n_shapes+1] uint32
+    uint32_t *lds_off = reinterpret_cast<uint32_t *>(lds + 3 * shapes.total_verts);
+    for (uint32_t k = threadIdx.x; k < 3 * shapes.total_verts; k += blockDim.x)
+        lds[k] = shapes.verts[k];
+    for (uint32_t k = threadIdx.x; k <= shapes.n_shapes; k += blockDim.x)
+        lds_off[k] = shapes.offsets[k];
+    __syncthreads();
+
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t st = b.stride;
+
+    BodyStatic s;
+    s.inv_mass = b.stat[(size_t)S_INV_MASS * st + i];
+    s.inv_inertia.cx = load3(b.stat, S_INV_INERTIA + 0, st, i);
+    s.inv_inertia.cy = load3(b.stat, S_INV_INERTIA + 3, st, i);
+    s.inv_inertia.cz = load3(b.stat, S_INV_INERTIA + 6, st, i);
+    s.ext_force = load3(b.stat, S_EXT_FORCE, st, i);
+    s.int_force = load3(b.stat, S_INT_FORCE, st, i);
+    s.ext_torque = load3(b.stat, S_EXT_TORQUE, st, i);
+    s.int_torque = load3(b.stat, S_INT_TORQUE, st, i);
+    s.com = load3(b.stat, S_COM, st, i);
+
+    BodyDynamic d;
+    d.pos = load3(b.dyn, D_POS, st, i);
+    d.rot = Quat{b.dyn[(size_t)(D_ROT + 0) * st + i], b.dyn[(size_t)(D_ROT + 1) * st + i],
+                 b.dyn[(size_t)(D_ROT + 2) * st + i], b.dyn[(size_t)(D_ROT + 3) * st + i]};
+    d.vel = load3(b.dyn, D_VEL, st, i);
+    d.ang = load3(b.dyn, D_ANG, st, i);
+
+    const uint32_t sid = b.shape_id[i];
+    const uint32_t v0 = lds_off[sid];
+    const uint32_t nv = lds_off[sid + 1] - v0;
+    const double *verts = lds + 3 * v0;
+
+    const double compliance = 1e-6 / (h * h); // src/solver.rs:20
+
+    uint32_t mask = 0;
+    for (uint32_t k = 0; k < substeps; ++k) {
+        mask = substep(d, s, h, compliance, verts, nv);
+        if (TRACE)
+            trace_masks[(size_t)(trace_row0 + k) * st + i] = mask;
+    }
+
+    store3(b.dyn, D_POS, st, i, d.pos);
+    b.dyn[(size_t)(D_ROT + 0) * st + i] = d.rot.s;
+    b.dyn[(size_t)(D_ROT + 1) * st + i] = d.rot.x;
+    b.dyn[(size_t)(D_ROT + 2) * st + i] = d.rot.y;
+    b.dyn[(size_t)(D_ROT + 3) * st + i] = d.rot.z;
+    store3(b.dyn, D_VEL, st, i, d.vel);
+    store3(b.dyn, D_ANG, st, i, d.ang);
+    last_mask[i] = mask;
+}
+
+// ---------------------------------------------------------------------------
+// AoS <-> SoA.  A block moves 64 bodies: the 64*38-double AoS chunk is one
+// contiguous range (coalesced) and is transposed through LDS into 38
+// contiguous 512-byte field segments.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTile = 64;
+
+// AoS double index of SoA field f (dyn first, then stat); see xpbd.h xpbd_rigid.
+__device__ __forceinline__ uint32_t aos_index_of_dyn(uint32_t f)
+{
+    // pos 31-33, rot 34-37, vel 22-24, ang 25-27
+    return f < 7 ? 31 + f : (f < 10 ? 22 + (f - 7) : 25 + (f - 10));
+}
+__device__ __forceinline__ uint32_t aos_index_of_stat(uint32_t f)
+{
+    // 0..21 identical; com 28-30
+    return f < 22 ? f : 28 + (f - 22);
+}
+
+__global__ void k_aos_to_soa(const double *__restrict__ aos, BodyArrays b)
+{
+    __shared__ double tile[kTile * kRigidDoubles];
+    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t count = min(kTile, b.n - base);
+    const size_t src0 = (size_t)base * kRigidDoubles;
+    for (uint32_t k = threadIdx.x; k < count * kRigidDoubles; k += blockDim.x)
+        tile[k] = aos[src0 + k];
+    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    if (t >= count)
+        return;
+    for (uint32_t f = 0; f < kDynFields; ++f)
+        b.dyn[(size_t)f * b.stride + base + t] = tile[t * kRigidDoubles + aos_index_of_dyn(f)];
+    for (uint32_t f = 0; f < kStatFields; ++f)
+        b.stat[(size_t)f * b.stride + base + t] = tile[t * kRigidDoubles + aos_index_of_stat(f)];
+}
+
+__global__ void k_soa_to_aos(BodyArrays b, double *__restrict__ aos)
+{
+    __shared__ double tile[kTile * kRigidDoubles];
+    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t count = min(kTile, b.n - base);
+    const uint32_t t = threadIdx.x;
+    if (t < count) {
+        for (uint32_t f = 0; f < kDynFields; ++f)
+            tile[t * kRigidDoubles + aos_index_of_dyn(f)] = b.dyn[(size_t)f * b.stride + base + t];
+        for (uint32_t f = 0; f < kStatFields; ++f)
+            tile[t * kRigidDoubles + aos_index_of_stat(f)] = b.stat[(size_t)f * b.stride + base + t];
+    }
+    __syncthreads();
+    const size_t dst0 = (size_t)base * kRigidDoubles;
+    for (uint32_t k = threadIdx.x; k < count * kRigidDoubles; k += blockDim.x)
+        aos[dst0 + k] = tile[k];
+}
+
+// ---------------------------------------------------------------------------
+// Contact list: per-body masks -> (body, vertex) pairs sorted by body, vertex.
+// Two passes over the masks with a block-level scan in between.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kScanBlock = 256;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d, 64);
+        if (lane >= d)
+            v += up;
+    }
+    return v;
+}
+
+// Exclusive scan across a 256-thread block; returns the block total via *total.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total)
+{
+    __shared__ uint32_t wave_sum[kScanBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63)
+        wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanBlock / 64; ++k) {
+        const uint32_t ws = wave_sum[k];
+        if (k < wave)
+            before += ws;
+        all += ws;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ void k_contacts_block_count(const uint32_t *__restrict__ mask, uint32_t n,
+                                       uint32_t *__restrict__ block_counts)
+{
+    const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t c = i < n ? __popc(mask[i]) : 0u;
+    uint32_t total;
+    (void)block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = total;
+}
+
+// Single block: in-place exclusive scan of block_counts[0..nb), total -> [nb].
+__global__ void k_contacts_scan_blocks(uint32_t *__restrict__ block_counts, uint32_t nb)
+{
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += kScanBlock) {
+        const uint32_t k = base + threadIdx.x;
+        const uint32_t v = k < nb ? block_counts[k] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, &total);
+        const uint32_t carry = carry_s;
+        if (k < nb)
+            block_counts[k] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        block_counts[nb] = carry_s;
+}
+
+__global__ void k_contacts_emit(const uint32_t *__restrict__ mask, uint32_t n,
+                                const uint32_t *__restrict__ block_offsets,
+                                xpbd_contact *__restrict__ out, uint32_t cap)
+{
+    const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+    uint32_t m = i < n ? mask[i] : 0u;
+    uint32_t total;
+    uint32_t at = block_offsets[blockIdx.x] + block_exclusive_scan(__popc(m), &total);
+    while (m) {
+        const uint32_t v = __ffs(m) - 1;
+        m &= m - 1;
+        if (at < cap)
+            out[at] = xpbd_contact{i, v};
+        ++at;
+    }
+}
+
+__global__ void k_selftest_div_sqrt(const double *__restrict__ a, const double *__restrict__ b,
+                                    double *__restrict__ q, double *__restrict__ r, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        q[i] = a[i] / b[i];
+        r[i] = sqrt(a[i]);
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_step(const BodyArrays &b, const ShapeTable &s, double h, uint32_t substeps,
+                       uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row0,
+                       uint32_t block_size, hipStream_t stream)
+{
+    if (b.n == 0)
+        return hipSuccess;
+    const uint32_t grid = (b.n + block_size - 1) / block_size;
+    const size_t lds_bytes = (size_t)s.total_verts * 3 * sizeof(double) + (size_t)(s.n_shapes + 1) * sizeof(uint32_t);
+    if (trace_masks)
+        hipLaunchKernelGGL(k_step<true>, dim3(grid), dim3(block_size), lds_bytes, stream, b, s, h, substeps,
+                           last_mask, trace_masks, trace_row0);
+    else
+        hipLaunchKernelGGL(k_step<false>, dim3(grid), dim3(block_size), lds_bytes, stream, b, s, h, substeps,
+                           last_mask, trace_masks, trace_row0);
+    return hipGetLastError();
+}
+
+hipError_t launch_aos_to_soa(const double *aos, const BodyArrays &b, hipStream_t stream)
+{
+    if (b.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((b.n + kTile - 1) / kTile), dim3(kTile), 0, stream, aos, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_soa_to_aos(const BodyArrays &b, double *aos, hipStream_t stream)
+{
+    if (b.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((b.n + kTile - 1) / kTile), dim3(kTile), 0, stream, b, aos);
+    return hipGetLastError();
+}
+
+hipError_t launch_contacts_count(const uint32_t *mask, uint32_t n, uint32_t *block_counts, hipStream_t stream)
+{
+    const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
+    if (nb)
+        hipLaunchKernelGGL(k_contacts_block_count, dim3(nb), dim3(kScanBlock), 0, stream, mask, n, block_counts);
+    hipLaunchKernelGGL(k_contacts_scan_blocks, dim3(1), dim3(kScanBlock), 0, stream, block_counts, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_contacts_emit(const uint32_t *mask, uint32_t n, const uint32_t *block_counts,
+                                xpbd_contact *out, uint32_t cap, hipStream_t stream)
+{
+    const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
+    if (nb)
+        hipLaunchKernelGGL(k_contacts_emit, dim3(nb), dim3(kScanBlock), 0, stream, mask, n, block_counts, out, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, uint32_t n,
+                                    hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_selftest_div_sqrt, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, q, r, n);
+    return hipGetLastError();
+}
+
+} // namespace xpbd

@@ -1,0 +1,466 @@
+// xpbd_world.cpp -- implementation of the C ABI in include/xpbd.h.
+//
+// Owns the device-side SoA body arrays, the shape tables and the HIP stream of
+// one world, and turns each ABI call into kernel launches from xpbd_kernels.hip.
+// There is no CPU fallback: without a usable HIP device every compute entry
+// point fails with XPBD_E_NO_DEVICE / XPBD_E_HIP.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "xpbd_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define XPBD_HIP_TRY(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? XPBD_E_OOM : XPBD_E_HIP, "%s failed: %s",      \
+                        #expr, hipGetErrorString(e_));                                             \
+    } while (0)
+
+uint32_t round_up(uint32_t v, uint32_t to) { return (v + to - 1) / to * to; }
+
+// A device allocation that only ever grows.
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+
+    hipError_t reserve(size_t want)
+    {
+        if (want <= bytes)
+            return hipSuccess;
+        if (ptr) {
+            hipError_t e = hipFree(ptr);
+            ptr = nullptr;
+            bytes = 0;
+            if (e != hipSuccess)
+                return e;
+        }
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess)
+            bytes = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+} // namespace
+
+struct xpbd_world {
+    int device = 0;
+    uint32_t mode = XPBD_MODE_FUSED;
+    uint32_t flags = 0;
+    uint32_t block_size = 0;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // bodies
+    uint32_t n = 0;
+    uint32_t stride = 0;
+    DeviceBuffer dyn, stat, shape_id, aos_staging, last_mask, trace, block_counts, contacts;
+    uint32_t trace_rows = 0; // substeps recorded by the last step()
+    bool stepped = false;
+
+    // shapes
+    DeviceBuffer shape_verts, shape_offsets;
+    uint32_t n_shapes = 0, total_verts = 0;
+    std::vector<uint32_t> host_offsets;
+
+    xpbd::BodyArrays arrays() const
+    {
+        return xpbd::BodyArrays{dyn.as<double>(), stat.as<double>(), shape_id.as<uint32_t>(), stride, n};
+    }
+    xpbd::ShapeTable shapes() const
+    {
+        return xpbd::ShapeTable{shape_verts.as<double>(), shape_offsets.as<uint32_t>(), n_shapes, total_verts};
+    }
+};
+
+namespace {
+
+constexpr uint32_t kDefaultBlock = 64;
+
+int bind_device(const xpbd_world *w)
+{
+    XPBD_HIP_TRY(hipSetDevice(w->device));
+    return XPBD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t xpbd_abi_version(void) { return XPBD_ABI_VERSION; }
+
+const char *xpbd_last_error(void) { return g_last_error.c_str(); }
+
+void xpbd_config_default(xpbd_config *cfg)
+{
+    if (!cfg)
+        return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->device = 0;
+    cfg->mode = XPBD_MODE_FUSED;
+}
+
+int xpbd_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+        return fail(XPBD_E_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+int xpbd_world_create(xpbd_world **out, const xpbd_config *cfg)
+{
+    if (!out)
+        return fail(XPBD_E_INVALID, "xpbd_world_create: out is NULL");
+    *out = nullptr;
+    xpbd_config c;
+    xpbd_config_default(&c);
+    if (cfg) {
+        if (cfg->struct_size != sizeof(xpbd_config))
+            return fail(XPBD_E_INVALID, "xpbd_world_create: struct_size %u != %zu", cfg->struct_size,
+                        sizeof(xpbd_config));
+        c = *cfg;
+    }
+    if (c.mode != XPBD_MODE_FUSED && c.mode != XPBD_MODE_PER_SUBSTEP)
+        return fail(XPBD_E_INVALID, "xpbd_world_create: unknown mode %u", c.mode);
+    if (c.flags & ~XPBD_FLAG_TRACE_CONTACTS)
+        return fail(XPBD_E_INVALID, "xpbd_world_create: unknown flags 0x%x", c.flags);
+    if (c.block_size != 0 && (c.block_size % 64 != 0 || c.block_size > 1024))
+        return fail(XPBD_E_INVALID, "xpbd_world_create: block_size %u must be a multiple of 64, <= 1024",
+                    c.block_size);
+    if (c.reserved[0] || c.reserved[1] || c.reserved[2])
+        return fail(XPBD_E_INVALID, "xpbd_world_create: reserved fields must be 0");
+
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(XPBD_E_NO_DEVICE, "no HIP device available (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (c.device < 0 || c.device >= count)
+        return fail(XPBD_E_INVALID, "xpbd_world_create: device %d out of range [0,%d)", c.device, count);
+
+    xpbd_world *w = new (std::nothrow) xpbd_world;
+    if (!w)
+        return fail(XPBD_E_OOM, "xpbd_world_create: host allocation failed");
+    w->device = c.device;
+    w->mode = c.mode;
+    w->flags = c.flags;
+    w->block_size = c.block_size ? c.block_size : kDefaultBlock;
+    e = hipSetDevice(w->device);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete w;
+        return fail(XPBD_E_HIP, "xpbd_world_create: stream creation failed: %s", hipGetErrorString(e));
+    }
+    w->stream = w->own_stream;
+    *out = w;
+    return XPBD_OK;
+}
+
+void xpbd_world_destroy(xpbd_world *w)
+{
+    if (!w)
+        return;
+    (void)hipSetDevice(w->device);
+    if (w->stream)
+        (void)hipStreamSynchronize(w->stream);
+    for (DeviceBuffer *b : {&w->dyn, &w->stat, &w->shape_id, &w->aos_staging, &w->last_mask, &w->trace,
+                            &w->block_counts, &w->contacts, &w->shape_verts, &w->shape_offsets})
+        b->release();
+    if (w->own_stream)
+        (void)hipStreamDestroy(w->own_stream);
+    delete w;
+}
+
+int xpbd_world_set_shapes(xpbd_world *w, const double *verts_xyz, const uint32_t *vert_offsets,
+                          uint32_t n_shapes)
+{
+    if (!w || !verts_xyz || !vert_offsets || n_shapes == 0)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: NULL argument or no shapes");
+    if (vert_offsets[0] != 0)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: vert_offsets[0] must be 0");
+    for (uint32_t s = 0; s < n_shapes; ++s) {
+        if (vert_offsets[s + 1] < vert_offsets[s])
+            return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: vert_offsets not monotone at %u", s);
+        if (vert_offsets[s + 1] - vert_offsets[s] > XPBD_MAX_SHAPE_VERTS)
+            return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: shape %u has %u vertices (max %u)", s,
+                        vert_offsets[s + 1] - vert_offsets[s], XPBD_MAX_SHAPE_VERTS);
+    }
+    const uint32_t total = vert_offsets[n_shapes];
+    // The tables are staged into LDS by every block; keep them far below the 160 KiB/CU.
+    if ((size_t)total * 24 + (size_t)(n_shapes + 1) * 4 > 48 * 1024)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: shape tables exceed 48 KiB");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    XPBD_HIP_TRY(w->shape_verts.reserve(total ? (size_t)total * 24 : 8));
+    XPBD_HIP_TRY(w->shape_offsets.reserve((size_t)(n_shapes + 1) * 4));
+    if (total)
+        XPBD_HIP_TRY(hipMemcpy(w->shape_verts.ptr, verts_xyz, (size_t)total * 24, hipMemcpyHostToDevice));
+    XPBD_HIP_TRY(hipMemcpy(w->shape_offsets.ptr, vert_offsets, (size_t)(n_shapes + 1) * 4, hipMemcpyHostToDevice));
+    w->n_shapes = n_shapes;
+    w->total_verts = total;
+    w->host_offsets.assign(vert_offsets, vert_offsets + n_shapes + 1);
+    return XPBD_OK;
+}
+
+int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_t *shape_id, uint32_t n)
+{
+    if (!w || (!aos && n))
+        return fail(XPBD_E_INVALID, "xpbd_world_upload_bodies: NULL argument");
+    if (w->n_shapes == 0)
+        return fail(XPBD_E_INVALID, "xpbd_world_upload_bodies: call xpbd_world_set_shapes first");
+    if (shape_id)
+        for (uint32_t i = 0; i < n; ++i)
+            if (shape_id[i] >= w->n_shapes)
+                return fail(XPBD_E_INVALID, "xpbd_world_upload_bodies: shape_id[%u] = %u >= n_shapes %u", i,
+                            shape_id[i], w->n_shapes);
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint32_t stride = round_up(n ? n : 1, 256);
+    XPBD_HIP_TRY(w->dyn.reserve((size_t)xpbd::kDynFields * stride * 8));
+    XPBD_HIP_TRY(w->stat.reserve((size_t)xpbd::kStatFields * stride * 8));
+    XPBD_HIP_TRY(w->shape_id.reserve((size_t)stride * 4));
+    XPBD_HIP_TRY(w->last_mask.reserve((size_t)stride * 4));
+    XPBD_HIP_TRY(w->aos_staging.reserve((size_t)(n ? n : 1) * sizeof(xpbd_rigid)));
+    w->n = n;
+    w->stride = stride;
+    w->stepped = false;
+    w->trace_rows = 0;
+    if (n == 0)
+        return XPBD_OK;
+    XPBD_HIP_TRY(hipMemcpyAsync(w->aos_staging.ptr, aos, (size_t)n * sizeof(xpbd_rigid), hipMemcpyHostToDevice,
+                                w->stream));
+    if (shape_id)
+        XPBD_HIP_TRY(hipMemcpyAsync(w->shape_id.ptr, shape_id, (size_t)n * 4, hipMemcpyHostToDevice, w->stream));
+    else
+        XPBD_HIP_TRY(hipMemsetAsync(w->shape_id.ptr, 0, (size_t)stride * 4, w->stream));
+    XPBD_HIP_TRY(hipMemsetAsync(w->last_mask.ptr, 0, (size_t)stride * 4, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_aos_to_soa(w->aos_staging.as<double>(), w->arrays(), w->stream));
+    // The caller's buffers are only borrowed for the duration of the call.
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_download_bodies(xpbd_world *w, xpbd_rigid *aos, uint32_t n)
+{
+    if (!w || (!aos && n))
+        return fail(XPBD_E_INVALID, "xpbd_world_download_bodies: NULL argument");
+    if (n != w->n)
+        return fail(XPBD_E_INVALID, "xpbd_world_download_bodies: n = %u but the world holds %u bodies", n, w->n);
+    if (n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_soa_to_aos(w->arrays(), w->aos_staging.as<double>(), w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(aos, w->aos_staging.ptr, (size_t)n * sizeof(xpbd_rigid), hipMemcpyDeviceToHost,
+                                w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
+uint32_t xpbd_world_body_count(const xpbd_world *w) { return w ? w->n : 0; }
+
+int xpbd_world_step(xpbd_world *w, double dt, uint32_t substeps)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_step: NULL world");
+    if (substeps == 0) // the reference divides by zero and runs no substep; treat as an argument error
+        return fail(XPBD_E_INVALID, "xpbd_world_step: substeps must be > 0");
+    if (w->n_shapes == 0)
+        return fail(XPBD_E_INVALID, "xpbd_world_step: no shapes set");
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    const double h = dt / (double)substeps; // src/solver.rs:4
+    uint32_t *trace = nullptr;
+    if (w->flags & XPBD_FLAG_TRACE_CONTACTS) {
+        XPBD_HIP_TRY(hipStreamSynchronize(w->stream)); // reserve() may free the previous buffer
+        XPBD_HIP_TRY(w->trace.reserve((size_t)substeps * w->stride * 4));
+        trace = w->trace.as<uint32_t>();
+        w->trace_rows = substeps;
+    }
+    if (w->mode == XPBD_MODE_FUSED) {
+        XPBD_HIP_TRY(xpbd::launch_step(w->arrays(), w->shapes(), h, substeps, w->last_mask.as<uint32_t>(), trace, 0,
+                                       w->block_size, w->stream));
+    } else {
+        for (uint32_t k = 0; k < substeps; ++k)
+            XPBD_HIP_TRY(xpbd::launch_step(w->arrays(), w->shapes(), h, 1, w->last_mask.as<uint32_t>(), trace, k,
+                                           w->block_size, w->stream));
+    }
+    w->stepped = true;
+    return XPBD_OK;
+}
+
+int xpbd_world_synchronize(xpbd_world *w)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_synchronize: NULL world");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_download_contacts(xpbd_world *w, xpbd_contact *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!w || !n_out || (!out && cap))
+        return fail(XPBD_E_INVALID, "xpbd_world_download_contacts: NULL argument");
+    *n_out = 0;
+    if (w->n == 0 || !w->stepped)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    const uint32_t nb = (w->n + 255) / 256;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    XPBD_HIP_TRY(w->block_counts.reserve((size_t)(nb + 1) * 4));
+    XPBD_HIP_TRY(xpbd::launch_contacts_count(w->last_mask.as<uint32_t>(), w->n, w->block_counts.as<uint32_t>(),
+                                             w->stream));
+    uint32_t total = 0;
+    XPBD_HIP_TRY(hipMemcpyAsync(&total, w->block_counts.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    *n_out = total;
+    const uint32_t take = total < cap ? total : cap;
+    if (take) {
+        XPBD_HIP_TRY(w->contacts.reserve((size_t)take * sizeof(xpbd_contact)));
+        XPBD_HIP_TRY(xpbd::launch_contacts_emit(w->last_mask.as<uint32_t>(), w->n, w->block_counts.as<uint32_t>(),
+                                                w->contacts.as<xpbd_contact>(), take, w->stream));
+        XPBD_HIP_TRY(hipMemcpyAsync(out, w->contacts.ptr, (size_t)take * sizeof(xpbd_contact), hipMemcpyDeviceToHost,
+                                    w->stream));
+        XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    if (total > cap)
+        return fail(XPBD_E_CAPACITY, "xpbd_world_download_contacts: %u contacts, capacity %u", total, cap);
+    return XPBD_OK;
+}
+
+int xpbd_world_download_contact_masks(xpbd_world *w, uint32_t *masks, uint32_t substeps, uint32_t n)
+{
+    if (!w || !masks)
+        return fail(XPBD_E_INVALID, "xpbd_world_download_contact_masks: NULL argument");
+    if (!(w->flags & XPBD_FLAG_TRACE_CONTACTS))
+        return fail(XPBD_E_INVALID, "xpbd_world_download_contact_masks: world created without "
+                                    "XPBD_FLAG_TRACE_CONTACTS");
+    if (n != w->n || substeps != w->trace_rows)
+        return fail(XPBD_E_INVALID, "xpbd_world_download_contact_masks: asked for %u x %u, last step recorded %u x %u",
+                    substeps, n, w->trace_rows, w->n);
+    if (n == 0 || substeps == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipMemcpy2DAsync(masks, (size_t)n * 4, w->trace.ptr, (size_t)w->stride * 4, (size_t)n * 4, substeps,
+                                  hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_set_stream(xpbd_world *w, void *hip_stream)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_stream: NULL world");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    w->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : w->own_stream;
+    return XPBD_OK;
+}
+
+void *xpbd_world_get_stream(const xpbd_world *w) { return w ? static_cast<void *>(w->stream) : nullptr; }
+
+int xpbd_world_set_mode(xpbd_world *w, uint32_t mode)
+{
+    if (!w || (mode != XPBD_MODE_FUSED && mode != XPBD_MODE_PER_SUBSTEP))
+        return fail(XPBD_E_INVALID, "xpbd_world_set_mode: bad argument");
+    w->mode = mode;
+    return XPBD_OK;
+}
+
+int xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts, double dt, uint32_t substeps)
+{
+    if (!rigid || !verts_xyz)
+        return fail(XPBD_E_INVALID, "xpbd_step_one: NULL argument");
+    // One cached single-body world per host thread (the reference's step is re-entrant and
+    // stateless; so is this apart from the cache).
+    struct Cache {
+        xpbd_world *w = nullptr;
+        ~Cache() { xpbd_world_destroy(w); }
+    };
+    thread_local Cache cache;
+    if (!cache.w) {
+        xpbd_config cfg;
+        xpbd_config_default(&cfg);
+        if (int rc = xpbd_world_create(&cache.w, &cfg))
+            return rc;
+    }
+    const uint32_t offsets[2] = {0, nverts};
+    if (int rc = xpbd_world_set_shapes(cache.w, verts_xyz, offsets, 1))
+        return rc;
+    if (int rc = xpbd_world_upload_bodies(cache.w, rigid, nullptr, 1))
+        return rc;
+    if (int rc = xpbd_world_step(cache.w, dt, substeps))
+        return rc;
+    return xpbd_world_download_bodies(cache.w, rigid, 1);
+}
+
+int xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b, double *quotient, double *root,
+                           uint32_t n)
+{
+    if (n && (!a || !b || !quotient || !root))
+        return fail(XPBD_E_INVALID, "xpbd_selftest_div_sqrt: NULL argument");
+    if (n == 0)
+        return XPBD_OK;
+    XPBD_HIP_TRY(hipSetDevice(device));
+    DeviceBuffer buf;
+    const size_t bytes = (size_t)n * 8;
+    hipError_t e = buf.reserve(4 * bytes);
+    if (e != hipSuccess)
+        return fail(XPBD_E_OOM, "xpbd_selftest_div_sqrt: %s", hipGetErrorString(e));
+    double *d = buf.as<double>();
+    e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = xpbd::launch_selftest_div_sqrt(d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(quotient, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(root, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+    buf.release();
+    if (e != hipSuccess)
+        return fail(XPBD_E_HIP, "xpbd_selftest_div_sqrt: %s", hipGetErrorString(e));
+    return XPBD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,154 @@
+/*
+ * xpbd.h -- C ABI of the MI355X-native XPBD rigid-body stepper.
+ *
+ * This is the drop-in boundary for the per-substep hot path of
+ * jim-ec/constraint_solver: everything below `solver::step`
+ * (reference src/solver.rs:3-17) runs in hand-written HIP kernels for gfx950;
+ * everything above it (World, Rigid, Polytope construction, the app) stays on
+ * the host and calls these entry points.  Plain pointers and sizes only.
+ *
+ * Reference interface each entry point replaces:
+ *   xpbd_step_one               solver::step(&mut Rigid,&Polytope,dt,n)   src/solver.rs:3
+ *   xpbd_world_step             World::integrate's loop of solver::step    src/world.rs:34-43
+ *   xpbd_world_upload_bodies    the `&mut Rigid` borrows of that loop      src/world.rs:41-42, src/rigid.rs:6-50
+ *   xpbd_world_set_shapes       the `&Polytope` borrow (vertices only)     src/solver.rs:3, src/geometry.rs:82-93
+ *   xpbd_world_download_bodies  Rigid read-back (frame() for rendering)    src/app.rs:227-230, src/rigid.rs:75-80
+ *   xpbd_world_download_contacts  the Vec<Constraint> push order of ground src/collision.rs:16-32
+ *
+ * Semantics: for every body i,  xpbd_world_step(w, dt, n)  ==
+ *   solver::step(&mut body[i], &shape[shape_id[i]], dt, n)
+ * in IEEE f64 with the reference's operation order (no FMA contraction), so
+ * ground-contact index lists are bit-exact and poses agree with the CPU
+ * reference (target 1e-5 relative; observed bit-identical).
+ *
+ * Threading: one xpbd_world is used from one thread at a time; distinct worlds
+ * are independent.  step() enqueues on the world's HIP stream and returns;
+ * download_* and synchronize() wait.  No call throws or unwinds across the ABI.
+ */
+#ifndef XPBD_H
+#define XPBD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XPBD_ABI_VERSION 1u
+
+/* Error codes (reference has no Result on this path; it panics). */
+#define XPBD_OK                   0
+#define XPBD_E_INVALID          (-1)  /* bad argument / state */
+#define XPBD_E_HIP              (-2)  /* a HIP runtime call failed */
+#define XPBD_E_OOM              (-3)  /* host or device allocation failed */
+#define XPBD_E_SINGULAR_INERTIA (-4)  /* mirrors the panic at src/rigid.rs:59 */
+#define XPBD_E_NO_DEVICE        (-5)  /* no usable gfx950 device */
+#define XPBD_E_CAPACITY         (-6)  /* caller buffer too small */
+
+/* A shape may have at most this many vertices (contact set is a u32 mask). */
+#define XPBD_MAX_SHAPE_VERTS 32u
+
+/*
+ * repr(C) mirror of the reference's `Rigid` (src/rigid.rs:6-50), field order
+ * kept, `color` dropped: 38 doubles = 304 bytes.
+ *   inverse_inertia : cgmath Matrix3, column-major, [3*col + row]
+ *   rotation        : cgmath Quaternion::new(w, xi, yj, zk) order: {s, x, y, z}
+ */
+typedef struct xpbd_rigid {
+    double inverse_mass;
+    double inverse_inertia[9];
+    double external_force[3];
+    double internal_force[3];
+    double external_torque[3];
+    double internal_torque[3];
+    double velocity[3];
+    double angular_velocity[3];
+    double center_of_mass[3];
+    double position[3];
+    double rotation[4];
+} xpbd_rigid;
+
+/* One ground constraint of the last substep: body index and the index of the
+ * shape vertex that produced it (src/collision.rs:16-32 push order). */
+typedef struct xpbd_contact {
+    uint32_t body;
+    uint32_t vertex;
+} xpbd_contact;
+
+/* How xpbd_world_step schedules the substep loop. */
+#define XPBD_MODE_FUSED        0u /* one launch runs all substeps in registers (bodies are independent) */
+#define XPBD_MODE_PER_SUBSTEP  1u /* one launch per substep: state round-trips HBM each substep */
+
+#define XPBD_FLAG_TRACE_CONTACTS 1u /* keep the contact mask of every substep of the last step() call */
+
+typedef struct xpbd_config {
+    uint32_t struct_size;  /* = sizeof(xpbd_config) */
+    int32_t  device;       /* HIP device ordinal */
+    uint32_t mode;         /* XPBD_MODE_* */
+    uint32_t flags;        /* XPBD_FLAG_* */
+    uint32_t block_size;   /* threads per workgroup, multiple of 64; 0 = library default */
+    uint32_t reserved[3];  /* must be 0 */
+} xpbd_config;
+
+typedef struct xpbd_world xpbd_world;
+
+/* Library / error ---------------------------------------------------------- */
+uint32_t    xpbd_abi_version(void);
+/* Message for the last failing call on this thread; valid until the next call. */
+const char *xpbd_last_error(void);
+/* Fills cfg with defaults (device 0, fused mode, no flags). */
+void        xpbd_config_default(xpbd_config *cfg);
+/* Number of visible HIP devices, or a negative error code. */
+int         xpbd_device_count(void);
+
+/* World lifetime ----------------------------------------------------------- */
+int  xpbd_world_create(xpbd_world **out, const xpbd_config *cfg);
+void xpbd_world_destroy(xpbd_world *w);
+
+/* Shapes: all shapes' vertices back to back (xyz triples) and a CSR offset
+ * array of n_shapes+1 entries (in vertices).  Copied; caller keeps ownership. */
+int  xpbd_world_set_shapes(xpbd_world *w, const double *verts_xyz,
+                           const uint32_t *vert_offsets, uint32_t n_shapes);
+
+/* Bodies: AoS host array -> SoA device layout.  shape_id may be NULL (all 0). */
+int  xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos,
+                              const uint32_t *shape_id, uint32_t n);
+int  xpbd_world_download_bodies(xpbd_world *w, xpbd_rigid *aos, uint32_t n);
+uint32_t xpbd_world_body_count(const xpbd_world *w);
+
+/* for each body: solver::step(body, shape[body], dt, substeps).  Asynchronous. */
+int  xpbd_world_step(xpbd_world *w, double dt, uint32_t substeps);
+int  xpbd_world_synchronize(xpbd_world *w);
+
+/* Contacts of the LAST substep of the last step(), sorted by body then vertex
+ * (= reference push order).  *n_out receives the total count even when it
+ * exceeds cap (then XPBD_E_CAPACITY is returned and out holds the first cap). */
+int  xpbd_world_download_contacts(xpbd_world *w, xpbd_contact *out, uint32_t cap,
+                                  uint32_t *n_out);
+/* With XPBD_FLAG_TRACE_CONTACTS: masks[k*n + i] = bit set of shape vertices of
+ * body i that produced a constraint in substep k of the last step() call. */
+int  xpbd_world_download_contact_masks(xpbd_world *w, uint32_t *masks,
+                                       uint32_t substeps, uint32_t n);
+
+/* Stream interop: run on a caller-owned hipStream_t (NULL restores the
+ * world's own stream).  The caller keeps the stream alive. */
+int  xpbd_world_set_stream(xpbd_world *w, void *hip_stream);
+void *xpbd_world_get_stream(const xpbd_world *w);
+int  xpbd_world_set_mode(xpbd_world *w, uint32_t mode);
+
+/* Literal single-body drop-in for solver::step (src/solver.rs:3): uploads,
+ * steps on device 0 and downloads one body.  verts: nverts xyz triples. */
+int  xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts,
+                   double dt, uint32_t substeps);
+
+/* Diagnostics: quotient[i] = a[i] / b[i], root[i] = sqrt(a[i]) computed on the
+ * device with the stepper's own code generation.  Bit-exact contact lists need
+ * both to be correctly rounded; the parity tests check this against the host. */
+int  xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b,
+                            double *quotient, double *root, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XPBD_H */

@@ -1,0 +1,179 @@
+"""ctypes binding of oracle/libxpbd_oracle.so -- the CPU restatement of the reference.
+
+Test infrastructure: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Never by the product.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "libxpbd_oracle.so")
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+    def np(self):
+        return np.array([self.x, self.y, self.z])
+
+
+class Quat(C.Structure):
+    _fields_ = [("s", C.c_double), ("v", Vec3)]
+
+    def np(self):
+        return np.array([self.s, self.v.x, self.v.y, self.v.z])
+
+
+class Mat3(C.Structure):
+    _fields_ = [("x", Vec3), ("y", Vec3), ("z", Vec3)]
+
+    def np(self):  # [col][row]
+        return np.array([self.x.np(), self.y.np(), self.z.np()])
+
+
+class Frame(C.Structure):
+    _fields_ = [("position", Vec3), ("rotation", Quat)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("normal", Vec3), ("displacement", C.c_double)]
+
+
+class Rigid(C.Structure):
+    _fields_ = [("inverse_mass", C.c_double), ("inverse_inertia", Mat3), ("external_force", Vec3),
+                ("internal_force", Vec3), ("external_torque", Vec3), ("internal_torque", Vec3),
+                ("velocity", Vec3), ("angular_velocity", Vec3), ("center_of_mass", Vec3), ("position", Vec3),
+                ("rotation", Quat)]
+
+    def np(self):
+        return np.frombuffer(bytes(self), dtype=np.float64).copy()
+
+    @classmethod
+    def from_np(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(38)
+        return cls.from_buffer_copy(a.tobytes())
+
+
+class Constraint(C.Structure):
+    _fields_ = [("rigid", C.c_size_t), ("contact0", Vec3), ("contact1", Vec3), ("distance", C.c_double)]
+
+
+class Metrics(C.Structure):
+    _fields_ = [("mass", C.c_double), ("volume", C.c_double), ("center_of_mass", Vec3), ("inertia_tensor", Mat3)]
+
+
+class Polytope(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_edges", C.c_uint32), ("n_faces", C.c_uint32),
+                ("vertices", Vec3 * 32), ("edges", (C.c_uint32 * 2) * 64), ("face_offsets", C.c_uint32 * 33),
+                ("face_indices", C.c_uint32 * 128), ("centroid", Vec3)]
+
+    def verts(self):
+        return np.array([self.vertices[i].np() for i in range(self.n_vertices)])
+
+
+def vec3(a):
+    return Vec3(float(a[0]), float(a[1]), float(a[2]))
+
+
+def quat(a):
+    return Quat(float(a[0]), vec3(a[1:4]))
+
+
+def frame(pos, rot):
+    return Frame(vec3(pos), quat(rot))
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise ImportError("%s missing: run make -C oracle" % SO)
+    L = C.CDLL(SO)
+    P = C.POINTER
+    sig = {
+        "o_add": (Vec3, [Vec3, Vec3]), "o_sub": (Vec3, [Vec3, Vec3]), "o_dot": (C.c_double, [Vec3, Vec3]),
+        "o_cross": (Vec3, [Vec3, Vec3]), "o_magnitude": (C.c_double, [Vec3]), "o_normalize": (Vec3, [Vec3]),
+        "o_project_on": (Vec3, [Vec3, Vec3]), "o_qmul": (Quat, [Quat, Quat]), "o_qrot": (Vec3, [Quat, Vec3]),
+        "o_qconj": (Quat, [Quat]), "o_qnormalize": (Quat, [Quat]),
+        "o_quat_from_euler_deg": (Quat, [C.c_double] * 3), "o_mat3_mulv": (Vec3, [Mat3, Vec3]),
+        "o_mat3_invert": (C.c_int, [Mat3, P(Mat3)]),
+        "o_frame_inverse": (Frame, [Frame]), "o_frame_delta": (Vec3, [Frame, Frame, Vec3]),
+        "o_frame_mulv": (Vec3, [Frame, Vec3]), "o_frame_mulplane": (Plane, [Frame, Plane]),
+        "o_frame_mul": (Frame, [Frame, Frame]),
+        "o_plane_from_points": (Plane, [Vec3, Vec3, Vec3]), "o_plane_from_point_normal": (Plane, [Vec3, Vec3]),
+        "o_plane_distance": (C.c_double, [Plane, Vec3]),
+        "o_polytope_tetrahedron": (None, [P(Polytope)]), "o_polytope_cube": (None, [P(Polytope)]),
+        "o_polytope_icosahedron": (None, [P(Polytope)]), "o_polytope_scale": (None, [C.c_double, P(Polytope)]),
+        "o_polytope_plane": (Plane, [P(Polytope), C.c_uint32]),
+        "o_polytope_support": (Vec3, [P(Polytope), Frame, Vec3]),
+        "o_polytope_minkowski_support": (Vec3, [P(Polytope), Frame, Frame, Vec3]),
+        "o_rigid_metrics": (None, [P(Polytope), C.c_double, P(Metrics)]),
+        "o_rigid_new": (C.c_int, [P(Metrics), P(Rigid)]), "o_rigid_frame": (Frame, [P(Rigid)]),
+        "o_rigid_integrate": (None, [P(Rigid), C.c_double]),
+        "o_rigid_derive": (None, [P(Rigid), Vec3, Quat, C.c_double]),
+        "o_rigid_apply_impulse": (None, [P(Rigid), Vec3, Vec3]),
+        "o_constraint_current_distance": (C.c_double, [P(Constraint)]),
+        "o_constraint_inverse_resistance": (C.c_double, [P(Constraint), P(P(Rigid))]),
+        "o_constraint_act": (None, [P(Constraint), P(P(Rigid)), C.c_double]),
+        "o_ground": (C.c_uint32, [P(Rigid), Frame, P(Vec3), C.c_uint32, P(Constraint), P(C.c_uint32)]),
+        "o_face_axes_separation": (C.c_double, [Frame, Frame, P(Polytope), P(Polytope), P(C.c_uint64)]),
+        "o_edge_axes_separation": (C.c_double, [Frame, Frame, P(Polytope), P(Polytope), P(C.c_uint64), P(C.c_uint64)]),
+        "o_solve": (None, [P(Rigid), P(Constraint), C.c_uint32, C.c_double]),
+        "o_step": (None, [P(Rigid), P(Vec3), C.c_uint32, C.c_double, C.c_size_t, P(C.c_uint32)]),
+        "o_world_new": (C.c_int, [P(Polytope), P(Polytope), P(Rigid), P(Rigid)]),
+        "o_world_integrate": (None, [P(Rigid), P(Rigid), C.c_double, P(Polytope)]),
+        "o_step_bodies": (None, [C.c_void_p, P(C.c_uint32), C.c_uint32, P(C.c_double), P(C.c_uint32), C.c_double,
+                                 C.c_uint32, P(C.c_uint32), C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def polytope(kind, scale=1.0):
+    L = load()
+    p = Polytope()
+    {"cube": L.o_polytope_cube, "tetrahedron": L.o_polytope_tetrahedron,
+     "icosahedron": L.o_polytope_icosahedron}[kind](C.byref(p))
+    if scale != 1.0:
+        L.o_polytope_scale(scale, C.byref(p))
+    return p
+
+
+def step_bodies(bodies, shape_id, verts_xyz, vert_offsets, dt, substeps, want_masks=False, threads=1):
+    """oracle batch: for each body solver::step(...).  Returns (new bodies, masks or None)."""
+    L = load()
+    b = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
+    n = b.shape[0]
+    sid = np.ascontiguousarray(shape_id if shape_id is not None else np.zeros(n), dtype=np.uint32)
+    v = np.ascontiguousarray(verts_xyz, dtype=np.float64).reshape(-1)
+    if v.size == 0:
+        v = np.zeros(3)
+    off = np.ascontiguousarray(vert_offsets, dtype=np.uint32)
+    masks = np.zeros((substeps, n), dtype=np.uint32) if want_masks else None
+    u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    L.o_step_bodies(b.ctypes.data, sid.ctypes.data_as(u32p), n, v.ctypes.data_as(f64p), off.ctypes.data_as(u32p),
+                    dt, substeps, masks.ctypes.data_as(u32p) if want_masks else None, threads)
+    return b, masks
+
+
+def masks_to_contacts(mask_row):
+    """(body, vertex) list in reference push order from one substep's masks."""
+    out = []
+    for body in np.nonzero(mask_row)[0]:
+        m = int(mask_row[body])
+        v = 0
+        while m:
+            if m & 1:
+                out.append((int(body), v))
+            m >>= 1
+            v += 1
+    return np.array(out, dtype=np.uint32).reshape(-1, 2)

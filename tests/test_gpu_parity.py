@@ -1,0 +1,234 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bar (BASELINE.json north_star): contact indices bit-exact, poses within 1e-5 relative.
+The kernels keep the reference's operation order with FMA contraction off and the device's
+f64 divide and sqrt are correctly rounded, so the poses are asserted BIT-IDENTICAL too; the
+1e-5 bound is checked alongside so a future relaxation of bit-exactness is still gated."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from constraint_solver_amd import capi
+from golden_util import bits_equal, load, max_rel, unhex
+
+pytestmark = pytest.mark.gpu
+
+DT = 1.0 / 60.0
+MODES = [capi.MODE_FUSED, capi.MODE_PER_SUBSTEP]
+POSE = slice(31, 38)
+
+
+def assert_pose_parity(got, want):
+    assert max_rel(got[:, POSE], want[:, POSE]) <= 1e-5          # the north_star tolerance
+    assert bits_equal(got, want)                                  # what this implementation actually achieves
+
+
+def run_world(bodies, sid, verts, off, substeps, frames, mode, trace=True, block_size=0):
+    out_masks = []
+    with capi.World(mode=mode, trace_contacts=trace, block_size=block_size) as w:
+        w.set_shapes(verts, off)
+        w.upload(bodies, sid)
+        for _ in range(frames):
+            w.step(DT, substeps)
+            if trace:
+                out_masks.append(w.contact_masks(substeps))
+        return w.download(), out_masks, w.contacts()
+
+
+def test_device_divide_and_sqrt_are_correctly_rounded():
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(0, 4, 200000), np.exp(rng.uniform(-700, 700, 200000)),
+                        rng.uniform(1 - 1e-12, 1 + 1e-12, 100000), [0.0, 1.0, 4.0, 2.0 ** -1060, 5e-324, np.inf]])
+    b = np.concatenate([rng.uniform(-4, 4, 200000), np.exp(rng.uniform(-300, 300, 200000)),
+                        rng.uniform(1 - 1e-12, 1 + 1e-12, 100000), [3.0, 3.0, 7.0, 3.0, 2.0, 2.0]])
+    q, s = capi.selftest_div_sqrt(a, b)
+    with np.errstate(all="ignore"):
+        assert bits_equal(q, a / b)
+        assert bits_equal(s, np.sqrt(a))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_golden_world_new(mode):
+    d = load("world_new.json")
+    verts, off = unhex(d["verts"], (-1, 3)), np.array(d["vert_offsets"], dtype=np.uint32)
+    with capi.World(mode=mode, trace_contacts=True) as w:
+        w.set_shapes(verts, off)
+        w.upload(unhex(d["initial"], (2, 38)))
+        for f in range(60):
+            w.step(float.fromhex(d["dt"]), d["substeps"])
+            assert np.array_equal(w.contact_masks(d["substeps"]), np.array(d["masks"][f], dtype=np.uint32)), f
+            assert_pose_parity(w.download(), unhex(d["frames"][f], (2, 38)))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["config1_boxes32.json", "mixed48.json", "shapes_rest.json"])
+def test_golden_scenes(name, mode):
+    d = load(name)
+    n = len(d["shape_id"])
+    verts, off = unhex(d["verts"], (-1, 3)), np.array(d["vert_offsets"], dtype=np.uint32)
+    got, masks, contacts = run_world(unhex(d["initial"], (n, 38)), np.array(d["shape_id"], dtype=np.uint32), verts, off,
+                                     d["substeps"], d["n_frames"], mode)
+    assert np.array_equal(np.array(masks), np.array(d["masks"], dtype=np.uint32))
+    assert_pose_parity(got, unhex(d["final"], (n, 38)))
+    assert np.array_equal(contacts, ob.masks_to_contacts(np.array(d["masks"], dtype=np.uint32)[-1, -1]))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("kind,n,substeps,frames", [
+    (capi.SCENE_BOXES, 4096, 20, 6),          # BASELINE configs[1] body count, ground-contact (pinned) variant
+    (capi.SCENE_MIXED, 3001, 20, 6),          # ragged: not a multiple of 64 or 256, three vertex counts in one wave
+    (capi.SCENE_BOXES_DROP, 2048, 20, 45),    # the bench scene: fall, land, settle into resting contact
+    (capi.SCENE_MIXED_DROP, 1500, 4, 40),
+    (capi.SCENE_BOXES, 65, 1, 3),
+])
+def test_seeded_scene_vs_oracle(kind, n, substeps, frames, mode):
+    verts, off = capi.scene_shapes(kind)
+    bodies, sid = capi.scene_generate(kind, 2, n)
+    want, want_masks = bodies, []
+    for _ in range(frames):
+        want, m = ob.step_bodies(want, sid, verts, off, DT, substeps, want_masks=True, threads=8)
+        want_masks.append(m)
+    got, masks, contacts = run_world(bodies, sid, verts, off, substeps, frames, mode)
+    assert np.array_equal(np.array(masks), np.array(want_masks))         # contact indices of EVERY substep
+    assert_pose_parity(got, want)
+    assert np.array_equal(contacts, ob.masks_to_contacts(want_masks[-1][-1]))
+    assert np.array(want_masks).any()                                     # the case did exercise contacts
+
+
+@pytest.mark.parametrize("block_size", [64, 128, 256])
+def test_block_size_does_not_change_results(block_size):
+    verts, off = capi.scene_shapes(capi.SCENE_MIXED)
+    bodies, sid = capi.scene_generate(capi.SCENE_MIXED, 9, 1000)
+    want, _ = ob.step_bodies(bodies, sid, verts, off, DT, 20)
+    got, _, _ = run_world(bodies, sid, verts, off, 20, 1, capi.MODE_FUSED, trace=False, block_size=block_size)
+    assert bits_equal(got, want)
+
+
+def test_step_one_is_solver_step(oracle):
+    import ctypes as C
+    verts = ob.polytope("cube").verts()
+    bodies, _ = capi.scene_generate(capi.SCENE_BOXES, 3, 4)
+    for b in bodies:
+        r = ob.Rigid.from_np(b)
+        p = ob.polytope("cube")
+        oracle.o_step(C.byref(r), p.vertices, p.n_vertices, DT, 25, None)
+        assert bits_equal(capi.step_one(b, verts, DT, 25), r.np())
+
+
+# ---------------------------------------------------------------- edge cases
+def test_empty_world_and_single_body():
+    verts, off = capi.scene_shapes(capi.SCENE_BOXES)
+    with capi.World() as w:
+        w.set_shapes(verts, off)
+        w.upload(np.zeros((0, 38)))
+        w.step(DT, 20)
+        assert w.download().shape == (0, 38) and w.contacts().shape == (0, 2)
+        one, sid = capi.scene_generate(capi.SCENE_BOXES, 1, 1)
+        w.upload(one, sid)
+        w.step(DT, 20)
+        want, _ = ob.step_bodies(one, sid, verts, off, DT, 20)
+        assert bits_equal(w.download(), want)
+
+
+def test_shape_without_vertices_never_contacts():
+    bodies, _ = capi.scene_generate(capi.SCENE_BOXES, 1, 100)
+    verts = np.zeros((0, 3))
+    off = np.array([0, 0], dtype=np.uint32)
+    got, masks, contacts = run_world(bodies, None, verts, off, 20, 2, capi.MODE_FUSED)
+    want, _ = ob.step_bodies(bodies, None, verts, off, DT, 20)
+    want, _ = ob.step_bodies(want, None, verts, off, DT, 20)
+    assert bits_equal(got, want) and not np.array(masks).any() and len(contacts) == 0
+
+
+def test_maximum_vertex_count_shape():
+    rng = np.random.default_rng(5)
+    verts = rng.normal(size=(32, 3))
+    verts /= np.linalg.norm(verts, axis=1, keepdims=True) * 2.0          # 32 points on a sphere of radius 0.5
+    off = np.array([0, 32], dtype=np.uint32)
+    bodies, _ = capi.scene_generate(capi.SCENE_BOXES_DROP, 4, 300)
+    got, masks, _ = run_world(bodies, None, verts, off, 20, 30, capi.MODE_FUSED)
+    want, want_masks = bodies, []
+    for _ in range(30):
+        want, m = ob.step_bodies(want, None, verts, off, DT, 20, want_masks=True, threads=8)
+        want_masks.append(m)
+    assert np.array_equal(np.array(masks), np.array(want_masks)) and bits_equal(got, want)
+    assert (np.array(want_masks) >> 16).any()                             # high vertex indices did occur
+    with capi.World() as w:
+        with pytest.raises(capi.XpbdError) as e:
+            w.set_shapes(np.zeros((33, 3)), np.array([0, 33], dtype=np.uint32))
+        assert e.value.code == capi.E_INVALID
+
+
+def test_nan_and_degenerate_states_propagate_like_the_reference():
+    verts, off = capi.scene_shapes(capi.SCENE_BOXES)
+    bodies, sid = capi.scene_generate(capi.SCENE_BOXES, 6, 130)
+    bodies[3, 33] = np.nan                    # NaN height: `z >= 0` is false -> constraints with NaN (K6)
+    bodies[70, 34:38] = 0.0                   # zero quaternion: normalize divides by zero
+    bodies[99, 0] = 0.0                       # infinite mass
+    bodies[100, 33] = -1e300                  # absurd penetration
+    want, want_masks = ob.step_bodies(bodies, sid, verts, off, DT, 20, want_masks=True)
+    got, masks, _ = run_world(bodies, sid, verts, off, 20, 1, capi.MODE_FUSED)
+    assert np.isnan(want[3, POSE]).all() and np.isnan(want[70, POSE]).any()
+    assert np.array_equal(masks[0], want_masks)
+    # NaN payload/sign bits are not specified by IEEE for arithmetic results: compare NaN-ness there
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert bits_equal(np.where(nan, 0.0, got), np.where(nan, 0.0, want))
+
+
+def test_argument_errors():
+    verts, off = capi.scene_shapes(capi.SCENE_BOXES)
+    bodies, sid = capi.scene_generate(capi.SCENE_BOXES, 1, 10)
+    with capi.World() as w:
+        with pytest.raises(capi.XpbdError):
+            w.upload(bodies, sid)                       # shapes not set
+        w.set_shapes(verts, off)
+        with pytest.raises(capi.XpbdError):
+            w.upload(bodies, np.full(10, 5, dtype=np.uint32))   # shape id out of range
+        w.upload(bodies, sid)
+        with pytest.raises(capi.XpbdError):
+            w.step(DT, 0)
+        with pytest.raises(capi.XpbdError):
+            w.contact_masks(20)                         # world created without the trace flag
+        w.n = 11
+        with pytest.raises(capi.XpbdError):
+            w.download()
+        w.n = 10
+        w.step(DT, 4)
+        assert w.download().shape == (10, 38)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE sizes)
+@pytest.mark.parametrize("kind,n", [(capi.SCENE_BOXES_DROP, 262144), (capi.SCENE_MIXED, 65536)])
+def test_full_size_schedules_agree_and_shards_compose(kind, n):
+    """At the benchmark's size the oracle is too slow to run whole, so use properties the path
+    must have: (1) fused == per-substep launches, bit for bit; (2) step(dt, 20) == 20 x step(dt/20, 1);
+    (3) stepping two half-worlds == stepping the whole (bodies are independent);
+    (4) a strided sample of bodies matches the oracle exactly."""
+    verts, off = capi.scene_shapes(kind)
+    bodies, sid = capi.scene_generate(kind, 1, n)
+    frames, substeps = 3, 20
+    fused, _, contacts_f = run_world(bodies, sid, verts, off, substeps, frames, capi.MODE_FUSED, trace=False)
+    split, _, contacts_s = run_world(bodies, sid, verts, off, substeps, frames, capi.MODE_PER_SUBSTEP, trace=False)
+    assert bits_equal(fused, split) and np.array_equal(contacts_f, contacts_s)
+    with capi.World() as w:
+        w.set_shapes(verts, off)
+        w.upload(bodies, sid)
+        for _ in range(frames * substeps):
+            w.step(DT / substeps, 1)
+        assert bits_equal(w.download(), fused)
+    half = n // 2
+    lo, _, c_lo = run_world(bodies[:half], sid[:half], verts, off, substeps, frames, capi.MODE_FUSED, trace=False)
+    hi, _, c_hi = run_world(bodies[half:], sid[half:], verts, off, substeps, frames, capi.MODE_FUSED, trace=False)
+    assert bits_equal(np.concatenate([lo, hi]), fused)
+    c_hi = c_hi.copy()
+    c_hi[:, 0] += half
+    assert np.array_equal(np.concatenate([c_lo, c_hi]), contacts_f)
+    # contact list is sorted by (body, vertex) and within range
+    key = contacts_f[:, 0].astype(np.int64) * 64 + contacts_f[:, 1]
+    assert (np.diff(key) > 0).all() and contacts_f[:, 0].max() < n
+    pick = np.arange(0, n, 97)
+    want = bodies[pick]
+    for _ in range(frames):
+        want, _ = ob.step_bodies(want, sid[pick], verts, off, DT, substeps, threads=8)
+    assert bits_equal(fused[pick], want)
