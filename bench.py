@@ -66,7 +66,7 @@ def cpu_baseline(state, shape_id, verts, offsets, substeps, budget_s=12.0, sampl
                      "oracle/xpbd_oracle.c (C restatement of the reference, gcc -O2 -ffp-contract=off), 1 thread "
                      "like the single-threaded reference" % (n, frames, substeps, sec)}
     # all host cores, for information (the reference itself is single-threaded)
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), 16)        # a 1-GPU box's CPU share is 16 cores
     if cores > 1:
         f2 = max(2, frames // 2)
         t0 = time.perf_counter()
@@ -123,8 +123,12 @@ def main():
     world = capi.World(device=local_rank, mode=mode, block_size=args.block_size)
     world.set_shapes(verts, offsets)
     world.upload(bodies, shape_id)                       # inputs resident in HBM before any timing
-    stream = torch.cuda.current_stream()
-    world.set_stream(stream.cuda_stream)                 # so torch.cuda.Event brackets OUR launches
+    # Run on an explicit torch stream so torch.cuda.Event (HIP events) brackets OUR launches; the
+    # default stream's handle is 0, which the ABI reads as "use the world's own stream".
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    world.set_stream(stream.cuda_stream)
 
     for _ in range(args.warmup):
         world.step(FRAME_TIME, args.substeps)
@@ -176,6 +180,7 @@ def main():
                                   "once and the kernel is f64-VALU bound, not HBM bound" % args.substeps)
                          if mode == capi.MODE_FUSED else "one launch per substep: state round-trips HBM every substep"},
         }
+        result["config"]["ground_contacts_per_body_after_run"] = len(world.contacts()) / max(count, 1)
         if world_size == 1 and not args.no_cpu_baseline:
             state = world.download()
             result["cpu_baseline"] = cpu_baseline(state, shape_id, verts, offsets, args.substeps)

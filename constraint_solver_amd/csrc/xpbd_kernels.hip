@@ -61,10 +61,10 @@ __device__ __forceinline__ Vec3 frame_origin(Vec3 pos, Quat rot, Vec3 com)
 // (bit v set <=> shape vertex v produced a constraint, src/collision.rs:18).
 //
 // ground() only reads the post-integrate pose and the past frame, and solve()
-// consumes the constraints in push order, so the two reference loops are run
-// as one: constraint v is built from the frozen post-integrate frame `cur`
-// and immediately projected onto the live pose (pos, rot).  The arithmetic and
-// its order per constraint are exactly the reference's.
+// consumes the constraints in push order, so no constraint list is stored:
+// constraint v is rebuilt from the frozen post-integrate frame `cur` and
+// immediately projected onto the live pose (pos, rot).  The arithmetic and its
+// order per constraint are exactly the reference's.
 __device__ __forceinline__ uint32_t substep(BodyDynamic &d, const BodyStatic &s, double h, double compliance,
                                             const double *verts, uint32_t n_verts)
 {
@@ -90,13 +90,26 @@ __device__ __forceinline__ uint32_t substep(BodyDynamic &d, const BodyStatic &s,
     const Frame cur{frame_origin(d.pos, d.rot, s.com), d.rot};
     const Frame cur_inv = inverse(cur);
 
+    // Pass 1 -- the `position.z >= 0.0` test of every vertex (src/collision.rs:17-18).  Only the
+    // z component of frame * vertex is live here, so the compiler drops the x/y arithmetic.
+    // (A NaN height fails `>=` and therefore IS a contact, as in the reference.)
     uint32_t mask = 0;
     for (uint32_t v = 0; v < n_verts; ++v) {
         const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
+        const Vec3 x = cur * vertex;
+        if (!(x.z >= 0.0))
+            mask |= 1u << v;
+    }
+
+    // Pass 2 -- each lane walks ITS OWN penetrating vertices in ascending index order (the
+    // reference's push order).  Lane-compacting the contact work this way makes a wave run the
+    // expensive body max-over-lanes(contact count) times instead of once per shape vertex with
+    // most lanes masked off (resting boxes: ~4 instead of 8 trips, at twice the lane utilisation).
+    // Recomputing x for the chosen vertex repeats the pass-1 arithmetic exactly, so the bits match.
+    for (uint32_t todo = mask; todo != 0; todo &= todo - 1) {
+        const uint32_t v = __ffs(todo) - 1;
+        const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
         const Vec3 x = cur * vertex;          // src/collision.rs:17
-        if (x.z >= 0.0)                       // src/collision.rs:18
-            continue;
-        mask |= 1u << v;
 
         // src/collision.rs:22-29
         const Vec3 target{x.x, x.y, 0.0};
