@@ -181,6 +181,19 @@ def main():
                          if mode == capi.MODE_FUSED else "one launch per substep: state round-trips HBM every substep"},
         }
         result["config"]["ground_contacts_per_body_after_run"] = len(world.contacts()) / max(count, 1)
+        if world_size == 1:
+            # Informational, never `value`: the same frame when the boundary hands over HOST buffers
+            # (AoS upload over PCIe -> step -> AoS download), as a literal per-frame drop-in would.
+            state = world.download()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                world.upload(state, shape_id)
+                world.step(FRAME_TIME, args.substeps)
+                state = world.download()
+            per_frame = (time.perf_counter() - t0) / 3
+            result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": "body*substeps/s",
+                                        "ms_per_frame": per_frame * 1e3,
+                                        "what": "pageable host AoS upload + step + download every frame"}
         if world_size == 1 and not args.no_cpu_baseline:
             state = world.download()
             result["cpu_baseline"] = cpu_baseline(state, shape_id, verts, offsets, args.substeps)

@@ -1,0 +1,185 @@
+//! xpbd_ffi.rs -- Rust binding of include/xpbd.h for jim-ec/constraint_solver.
+//!
+//! NOT COMPILED IN THIS REPOSITORY: the build image has no rustc/cargo.  This is the
+//! binding a maintainer of the reference adds (as `src/xpbd_ffi.rs`, plus
+//! `println!("cargo:rustc-link-lib=dylib=xpbd_hip")` in build.rs) to run the per-substep
+//! hot path on an MI355X.  The compiled and tested equivalent in this repository is the C++
+//! host mirror `constraint_solver_amd/host/constraint_solver.hpp`, which calls the very same
+//! extern "C" entry points.
+//!
+//! What it replaces in the reference:
+//!   solver::step        src/solver.rs:3-17   -> xpbd_step_one      (literal, one body)
+//!   World::integrate    src/world.rs:34-43   -> xpbd_world_step    (batched, state stays in HBM)
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+use cgmath::{Matrix3, Quaternion, Vector3};
+
+use crate::{geometry::Polytope, rigid::Rigid};
+
+/// repr(C) mirror of `Rigid` (src/rigid.rs:6-50), `color` dropped: 38 f64.
+/// cgmath's own structs are not repr(C)-stable (Quaternion stores v before s in 0.18),
+/// so the conversion is spelled out field by field.
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct XpbdRigid {
+    pub inverse_mass: f64,
+    pub inverse_inertia: [f64; 9], // column-major, [3 * col + row]
+    pub external_force: [f64; 3],
+    pub internal_force: [f64; 3],
+    pub external_torque: [f64; 3],
+    pub internal_torque: [f64; 3],
+    pub velocity: [f64; 3],
+    pub angular_velocity: [f64; 3],
+    pub center_of_mass: [f64; 3],
+    pub position: [f64; 3],
+    pub rotation: [f64; 4], // s, x, y, z  (Quaternion::new argument order)
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct XpbdContact {
+    pub body: u32,
+    pub vertex: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct XpbdConfig {
+    pub struct_size: u32,
+    pub device: i32,
+    pub mode: u32,
+    pub flags: u32,
+    pub block_size: u32,
+    pub reserved: [u32; 3],
+}
+
+#[repr(C)]
+pub struct XpbdWorld {
+    _private: [u8; 0],
+}
+
+#[link(name = "xpbd_hip")]
+extern "C" {
+    pub fn xpbd_abi_version() -> u32;
+    pub fn xpbd_last_error() -> *const c_char;
+    pub fn xpbd_config_default(cfg: *mut XpbdConfig);
+    pub fn xpbd_device_count() -> c_int;
+    pub fn xpbd_world_create(out: *mut *mut XpbdWorld, cfg: *const XpbdConfig) -> c_int;
+    pub fn xpbd_world_destroy(w: *mut XpbdWorld);
+    pub fn xpbd_world_set_shapes(w: *mut XpbdWorld, verts_xyz: *const f64, vert_offsets: *const u32, n_shapes: u32) -> c_int;
+    pub fn xpbd_world_upload_bodies(w: *mut XpbdWorld, aos: *const XpbdRigid, shape_id: *const u32, n: u32) -> c_int;
+    pub fn xpbd_world_download_bodies(w: *mut XpbdWorld, aos: *mut XpbdRigid, n: u32) -> c_int;
+    pub fn xpbd_world_body_count(w: *const XpbdWorld) -> u32;
+    pub fn xpbd_world_step(w: *mut XpbdWorld, dt: f64, substeps: u32) -> c_int;
+    pub fn xpbd_world_synchronize(w: *mut XpbdWorld) -> c_int;
+    pub fn xpbd_world_download_contacts(w: *mut XpbdWorld, out: *mut XpbdContact, cap: u32, n_out: *mut u32) -> c_int;
+    pub fn xpbd_world_download_contact_masks(w: *mut XpbdWorld, masks: *mut u32, substeps: u32, n: u32) -> c_int;
+    pub fn xpbd_world_set_stream(w: *mut XpbdWorld, hip_stream: *mut c_void) -> c_int;
+    pub fn xpbd_world_get_stream(w: *const XpbdWorld) -> *mut c_void;
+    pub fn xpbd_world_set_mode(w: *mut XpbdWorld, mode: u32) -> c_int;
+    pub fn xpbd_step_one(rigid: *mut XpbdRigid, verts_xyz: *const f64, nverts: u32, dt: f64, substeps: u32) -> c_int;
+    pub fn xpbd_selftest_div_sqrt(device: i32, a: *const f64, b: *const f64, q: *mut f64, r: *mut f64, n: u32) -> c_int;
+}
+
+fn v3(v: Vector3<f64>) -> [f64; 3] {
+    [v.x, v.y, v.z]
+}
+
+fn from3(a: [f64; 3]) -> Vector3<f64> {
+    Vector3::new(a[0], a[1], a[2])
+}
+
+impl From<&Rigid> for XpbdRigid {
+    fn from(r: &Rigid) -> Self {
+        let m: &Matrix3<f64> = &r.inverse_inertia;
+        XpbdRigid {
+            inverse_mass: r.inverse_mass,
+            inverse_inertia: [m.x.x, m.x.y, m.x.z, m.y.x, m.y.y, m.y.z, m.z.x, m.z.y, m.z.z],
+            external_force: v3(r.external_force),
+            internal_force: v3(r.internal_force),
+            external_torque: v3(r.external_torque),
+            internal_torque: v3(r.internal_torque),
+            velocity: v3(r.velocity),
+            angular_velocity: v3(r.angular_velocity),
+            center_of_mass: v3(r.center_of_mass),
+            position: v3(r.position),
+            rotation: [r.rotation.s, r.rotation.v.x, r.rotation.v.y, r.rotation.v.z],
+        }
+    }
+}
+
+impl XpbdRigid {
+    /// Writes the dynamic state back; the static fields were never changed by the device.
+    pub fn store_into(&self, r: &mut Rigid) {
+        r.velocity = from3(self.velocity);
+        r.angular_velocity = from3(self.angular_velocity);
+        r.position = from3(self.position);
+        r.rotation = Quaternion::new(self.rotation[0], self.rotation[1], self.rotation[2], self.rotation[3]);
+    }
+}
+
+fn check(rc: c_int) {
+    if rc != 0 {
+        let msg = unsafe { CStr::from_ptr(xpbd_last_error()) }.to_string_lossy().into_owned();
+        // the reference panics on its own failure paths (src/rigid.rs:59); keep that contract
+        panic!("xpbd error {}: {}", rc, msg);
+    }
+}
+
+fn flat_vertices(polytope: &Polytope) -> Vec<f64> {
+    polytope.vertices.iter().flat_map(|v| [v.x, v.y, v.z]).collect()
+}
+
+/// Drop-in body for `solver::step` (src/solver.rs:3): same signature, same result.
+pub fn step(rigid: &mut Rigid, polytope: &Polytope, dt: f64, substep_count: usize) {
+    let mut c = XpbdRigid::from(&*rigid);
+    let verts = flat_vertices(polytope);
+    check(unsafe { xpbd_step_one(&mut c, verts.as_ptr(), polytope.vertices.len() as u32, dt, substep_count as u32) });
+    c.store_into(rigid);
+}
+
+/// N-body world resident on one GPU: upload once, `integrate` every frame, read poses back for rendering.
+pub struct GpuWorld {
+    handle: *mut XpbdWorld,
+    staging: Vec<XpbdRigid>,
+}
+
+impl GpuWorld {
+    pub fn new(device: i32, shapes: &[&Polytope], bodies: &[Rigid], shape_id: &[u32]) -> GpuWorld {
+        let mut cfg = XpbdConfig::default();
+        unsafe { xpbd_config_default(&mut cfg) };
+        cfg.device = device;
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { xpbd_world_create(&mut handle, &cfg) });
+        let mut verts = Vec::new();
+        let mut offsets = vec![0u32];
+        for p in shapes {
+            verts.extend(flat_vertices(p));
+            offsets.push((verts.len() / 3) as u32);
+        }
+        check(unsafe { xpbd_world_set_shapes(handle, verts.as_ptr(), offsets.as_ptr(), shapes.len() as u32) });
+        let staging: Vec<XpbdRigid> = bodies.iter().map(XpbdRigid::from).collect();
+        check(unsafe { xpbd_world_upload_bodies(handle, staging.as_ptr(), shape_id.as_ptr(), staging.len() as u32) });
+        GpuWorld { handle, staging }
+    }
+
+    /// World::integrate (src/world.rs:34-43) for every body: solver::step(body, shape, dt, substeps).
+    pub fn integrate(&mut self, dt: f64, substeps: u32) {
+        check(unsafe { xpbd_world_step(self.handle, dt, substeps) });
+    }
+
+    /// Read-back for rendering (src/app.rs:227-230 consumes Rigid::frame()).
+    pub fn read_back(&mut self, bodies: &mut [Rigid]) {
+        check(unsafe { xpbd_world_download_bodies(self.handle, self.staging.as_mut_ptr(), self.staging.len() as u32) });
+        for (c, r) in self.staging.iter().zip(bodies.iter_mut()) {
+            c.store_into(r);
+        }
+    }
+}
+
+impl Drop for GpuWorld {
+    fn drop(&mut self) {
+        unsafe { xpbd_world_destroy(self.handle) };
+    }
+}
