@@ -151,9 +151,12 @@ __device__ __forceinline__ uint32_t substep(BodyDynamic &d, const BodyStatic &s,
 // LDS: the shape vertex tables (<= a few hundred bytes), staged once per block.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kMaxStepBlock = 256;
+#ifndef XPBD_STEP_MIN_WAVES_PER_SIMD
+#define XPBD_STEP_MIN_WAVES_PER_SIMD 1
+#endif
 
 template <bool TRACE>
-__global__ void __launch_bounds__(kMaxStepBlock) k_step(BodyArrays b, ShapeTable shapes, double h, uint32_t substeps,
+__global__ void __launch_bounds__(kMaxStepBlock, XPBD_STEP_MIN_WAVES_PER_SIMD) k_step(BodyArrays b, ShapeTable shapes, double h, uint32_t substeps,
                        uint32_t *__restrict__ last_mask, uint32_t *__restrict__ trace_masks,
                        uint32_t trace_row0)
 {
