@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "xpbd_world_destroy", "xpbd_world_set_shapes", "xpbd_world_upload_bodies", "xpbd_world_download_bodies",
     "xpbd_world_body_count", "xpbd_world_step", "xpbd_world_synchronize", "xpbd_world_download_contacts",
     "xpbd_world_download_contact_masks", "xpbd_world_set_stream", "xpbd_world_get_stream", "xpbd_world_set_mode",
-    "xpbd_step_one", "xpbd_selftest_div_sqrt",
+    "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
 ]
 
 
@@ -51,6 +51,20 @@ class Config(C.Structure):
 
 _u32p = C.POINTER(C.c_uint32)
 _f64p = C.POINTER(C.c_double)
+
+
+class PolytopeDesc(C.Structure):
+    """xpbd_polytope"""
+    _fields_ = [("vertices_xyz", _f64p), ("edges", _u32p), ("face_offsets", _u32p), ("face_indices", _u32p),
+                ("n_vertices", C.c_uint32), ("n_edges", C.c_uint32), ("n_faces", C.c_uint32), ("reserved", C.c_uint32),
+                ("centroid", C.c_double * 3)]
+
+
+MAX_MANIFOLD_POINTS = 8
+FEATURE_FACE_A, FEATURE_FACE_B, FEATURE_EDGES = 0, 1, 2
+# xpbd_manifold as a numpy record (408 bytes)
+MANIFOLD_DTYPE = np.dtype([("n_points", "<u4"), ("feature", "<u4"), ("index_a", "<u4"), ("index_b", "<u4"),
+                           ("separation", "<f8"), ("p_ref", "<f8", (8, 3)), ("p_inc", "<f8", (8, 3))])
 
 
 def _load(name):
@@ -92,6 +106,8 @@ def hip_lib():
         L.xpbd_world_set_mode.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_step_one.argtypes = [C.c_void_p, _f64p, C.c_uint32, C.c_double, C.c_uint32]
         L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
+        L.xpbd_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
+        L.xpbd_world_narrowphase.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         _hip = L
     return _hip
 
@@ -112,6 +128,8 @@ def host_lib():
         L.xpbdh_rigid_frame.restype = None
         L.xpbdh_world_new.argtypes = [C.c_void_p, C.c_void_p]
         L.xpbdh_shape_plane.argtypes = [C.c_uint32, C.c_double, C.c_uint32, _f64p]
+        L.xpbdh_polytope_arrays.argtypes = [C.c_uint32, C.c_double, _u32p, _f64p, _u32p, _u32p, _u32p, _f64p]
+        L.xpbdh_polytope_arrays.restype = None
         _host = L
     return _host
 
@@ -193,6 +211,27 @@ class World:
     def contact_masks(self, substeps):
         out = np.empty((substeps, self.n), dtype=np.uint32)
         _check(hip_lib().xpbd_world_download_contact_masks(self._h, _u32(out), substeps, self.n))
+        return out
+
+    def set_polytopes(self, polytopes):
+        """polytopes: list of dicts with vertices (V,3), edges (E,2), face_offsets (F+1), face_indices, centroid (3)."""
+        keep, descs = [], (PolytopeDesc * len(polytopes))()
+        for d, p in zip(descs, polytopes):
+            v = np.ascontiguousarray(p["vertices"], dtype=np.float64).reshape(-1, 3)
+            e = np.ascontiguousarray(p["edges"], dtype=np.uint32).reshape(-1, 2)
+            fo = np.ascontiguousarray(p["face_offsets"], dtype=np.uint32)
+            fi = np.ascontiguousarray(p["face_indices"], dtype=np.uint32)
+            keep += [v, e, fo, fi]
+            d.vertices_xyz, d.edges, d.face_offsets, d.face_indices = _f64(v), _u32(e), _u32(fo), _u32(fi)
+            d.n_vertices, d.n_edges, d.n_faces = v.shape[0], e.shape[0], fo.size - 1
+            d.centroid[:] = [float(x) for x in p["centroid"]]
+        _check(hip_lib().xpbd_world_set_polytopes(self._h, descs, len(polytopes)))
+
+    def narrowphase(self, pairs):
+        """SAT manifolds (MANIFOLD_DTYPE records) of the given (A, B) body pairs at the current poses."""
+        pr = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros(pr.shape[0], dtype=MANIFOLD_DTYPE)
+        _check(hip_lib().xpbd_world_narrowphase(self._h, _u32(pr), pr.shape[0], out.ctypes.data))
         return out
 
     def set_stream(self, stream_ptr):
@@ -278,6 +317,26 @@ def world_new():
     if rc != OK:
         raise XpbdError(rc, "World::new failed")
     return a, b
+
+
+def polytope(shape, scale=1.0):
+    """Topology of a standard shape (host mirror's Polytope) as the dict World.set_polytopes takes."""
+    counts = np.zeros(4, dtype=np.uint32)
+    host_lib().xpbdh_polytope_arrays(shape, scale, _u32(counts), None, None, None, None, None)
+    v = np.zeros((counts[0], 3))
+    e = np.zeros((counts[1], 2), dtype=np.uint32)
+    fo = np.zeros(counts[2] + 1, dtype=np.uint32)
+    fi = np.zeros(counts[3], dtype=np.uint32)
+    c = np.zeros(3)
+    host_lib().xpbdh_polytope_arrays(shape, scale, _u32(counts), _f64(v), _u32(e), _u32(fo), _u32(fi), _f64(c))
+    return {"vertices": v, "edges": e, "face_offsets": fo, "face_indices": fi, "centroid": c}
+
+
+def scene_polytopes(kind):
+    """Polytopes of a scene kind, in shape-id order (matches scene_shapes)."""
+    if not (kind & 1):
+        return [polytope(SHAPE_CUBE)]
+    return [polytope(SHAPE_CUBE), polytope(SHAPE_TETRAHEDRON, 0.5), polytope(SHAPE_ICOSAHEDRON, 0.5)]
 
 
 def shape_planes(shape, scale=1.0):

@@ -15,8 +15,7 @@
 // math, not a contraction.  State lives in registers across substeps; shape
 // vertex tables sit in LDS; every global access is a contiguous 512-byte wave
 // access on the SoA arrays (xpbd_kernels.h).
-#include "xpbd_kernels.h"
-#include "xpbd_math.hpp"
+#include "xpbd_device.hpp"
 
 namespace xpbd {
 namespace {
@@ -37,25 +36,6 @@ struct BodyDynamic {
     Vec3 vel;
     Vec3 ang;
 };
-
-__device__ __forceinline__ Vec3 load3(const double *base, uint32_t field, uint32_t stride, uint32_t i)
-{
-    return Vec3{base[(size_t)(field + 0) * stride + i], base[(size_t)(field + 1) * stride + i],
-                base[(size_t)(field + 2) * stride + i]};
-}
-
-__device__ __forceinline__ void store3(double *base, uint32_t field, uint32_t stride, uint32_t i, Vec3 v)
-{
-    base[(size_t)(field + 0) * stride + i] = v.x;
-    base[(size_t)(field + 1) * stride + i] = v.y;
-    base[(size_t)(field + 2) * stride + i] = v.z;
-}
-
-// Rigid::frame().position  (src/rigid.rs:77): (position + com) + rotation * (-com)
-__device__ __forceinline__ Vec3 frame_origin(Vec3 pos, Quat rot, Vec3 com)
-{
-    return (pos + com) + rot * (-com);
-}
 
 // One substep of solver::step for one body.  Returns the ground-contact mask
 // (bit v set <=> shape vertex v produced a constraint, src/collision.rs:18).

@@ -130,4 +130,29 @@ XPBD_HD Frame operator*(const Frame &a, const Frame &b)
     return Frame{a.position + a.rotation * b.position, a.rotation * b.rotation};
 }
 
+// Plane in Hessian form (reference src/geometry.rs:9-12).
+struct Plane {
+    Vec3 normal;
+    double displacement;
+};
+
+// src/geometry.rs:27-36
+XPBD_HD Plane plane_from_point_normal(Vec3 point, Vec3 normal)
+{
+    double displacement = length(project_on(point, normal));
+    if (dot(point, normal) < 0.0)
+        displacement *= -1.0;
+    return Plane{normal, displacement};
+}
+
+// src/geometry.rs:39-41
+XPBD_HD double distance(const Plane &pl, Vec3 p) { return dot(pl.normal, p) - pl.displacement; }
+
+// Frame * Plane, src/frame.rs:55-64
+XPBD_HD Plane operator*(const Frame &f, const Plane &p)
+{
+    const Vec3 support = f * (p.displacement * p.normal);
+    return plane_from_point_normal(support, f.rotation * p.normal);
+}
+
 } // namespace xpbd

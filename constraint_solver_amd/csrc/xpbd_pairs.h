@@ -1,0 +1,54 @@
+// xpbd_pairs.h -- body-body contact EXTENSION: launchers for the
+// wave-per-pair SAT narrowphase in xpbd_pairs.hip.
+//
+// The reference has no body-body contacts: its `sat` (src/collision.rs:37-121) is an uncalled stub.
+// This extension finishes that sketch; conventions kept from the reference are listed next to the
+// code.  Parity for it is UNPINNED (own CPU oracle: oracle/xpbd_pairs_oracle.c).
+#pragma once
+
+#include <cstdint>
+#include <hip/hip_runtime_api.h>
+
+#include "xpbd_kernels.h"
+
+namespace xpbd {
+
+// Per-shape topology tables in device memory (all shapes back to back).
+struct ShapeDesc {
+    uint32_t vert0, n_verts;   // into verts (shared with ShapeTable::verts)
+    uint32_t face0, n_faces;   // into planes / face_start
+    uint32_t edge0, n_edges;   // into edges
+    uint32_t pad0, pad1;
+};
+
+struct PolytopeTables {
+    const double *verts;         // [total_verts][3]
+    const double *planes;        // [total_faces][4]  outward local plane (normal, displacement), Polytope::plane
+    const double *centroids;     // [n_shapes][3]
+    const ShapeDesc *desc;       // [n_shapes]
+    const uint32_t *face_start;  // [total_faces + 1] offsets into face_verts
+    const uint32_t *face_verts;  // shape-local vertex indices of every face, back to back
+    const uint32_t *edges;       // [total_edges][2] shape-local vertex indices
+    uint32_t n_shapes;
+};
+
+constexpr uint32_t kMaxManifoldPoints = 8;
+constexpr uint32_t kMaxFaceVerts = 8;      // vertices per face accepted by the clipper
+constexpr double kEdgeBias = 1e-6;         // an edge axis must beat both face axes by this much (metres)
+constexpr double kSupportTol = 1e-9;       // slack of the "edge is a supporting feature" tests (metres)
+
+// Result of one pair, 16-byte header + 8 x 2 points (xpbd_manifold in include/xpbd.h has this layout).
+struct Manifold {
+    uint32_t n_points;   // 0 = separated / not touching
+    uint32_t feature;    // 0 face of A, 1 face of B, 2 edge-edge
+    uint32_t index_a, index_b;
+    double separation;
+    double p_ref[kMaxManifoldPoints][3];
+    double p_inc[kMaxManifoldPoints][3];
+};
+
+// One wave per pair: pairs[2*p], pairs[2*p+1] are body indices (A, B).
+hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const uint32_t *pairs, uint32_t n_pairs,
+                            Manifold *out, hipStream_t stream);
+
+} // namespace xpbd

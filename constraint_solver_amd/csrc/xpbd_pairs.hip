@@ -1,0 +1,335 @@
+// xpbd_pairs.hip -- body-body contact EXTENSION: wave-per-pair SAT narrowphase for gfx950.
+//
+// The reference stops after the A-face query of `sat` (src/collision.rs:37-121, an uncalled
+// stub); this finishes the commented-out sketch there.  Parity is UNPINNED (no reference result
+// exists); the checker is oracle/xpbd_pairs_oracle.c.  Conventions kept from the reference:
+//   face_axes_separation  src/collision.rs:123-149  support = LAST maximum under f64::total_cmp,
+//                                                   face   = FIRST maximum ('>')
+//   edge_axes_separation  src/collision.rs:151-197  axis = normalize(eA x eB) flipped away from A's
+//                                                   centroid; pair skipped if A reaches past the foot;
+//                                                   parallel edges give a NaN axis and contribute nothing
+//   feature choice        src/collision.rs:47-59,89-92 (comments there)
+//   reference plane / incident face  src/collision.rs:66, 76-85 (first minimum of n . n_ref)
+//
+// Mapping: ONE WAVE = ONE CANDIDATE PAIR.  Both bodies' vertices are transformed once into LDS
+// (world space, and each into the other's local space); lanes then run in parallel over
+// faces x vertices, over the E_A x E_B edge pairs and over the incident body's faces, and combine
+// with __shfl_xor reductions that carry (value, index) so the reference's first/last tie-breaks
+// survive the parallel order.  Clipping (<= 4 planes x <= 8 points) runs on lane 0 out of LDS.
+#include <cfloat>
+
+#include "xpbd_device.hpp"
+#include "xpbd_pairs.h"
+
+namespace xpbd {
+namespace {
+
+constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS; // 32
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct PairLds {
+    double world[2][kMaxV][3]; // world-space vertices of A (0) and B (1)
+    double local[2][kMaxV][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space
+    double poly[2][16][3];     // clipping ping-pong
+};
+
+__device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
+__device__ __forceinline__ void st3(double (*a)[3], uint32_t k, Vec3 v)
+{
+    a[k][0] = v.x;
+    a[k][1] = v.y;
+    a[k][2] = v.z;
+}
+
+// Key whose signed-integer order is IEEE totalOrder (Rust f64::total_cmp).
+__device__ __forceinline__ long long total_key(double v)
+{
+    const long long i = __double_as_longlong(v);
+    return i ^ (long long)((unsigned long long)(i >> 63) >> 1);
+}
+
+__device__ __forceinline__ bool finite3(Vec3 v)
+{
+    return fabs(v.x) <= DBL_MAX && fabs(v.y) <= DBL_MAX && fabs(v.z) <= DBL_MAX;
+}
+
+// Vertex of `verts[0..n)` with the LAST maximal dot(v, dir) under the total order (Iterator::max_by).
+__device__ __forceinline__ Vec3 support_last_max(const double (*verts)[3], uint32_t n, Vec3 dir)
+{
+    Vec3 best = ld3(verts, 0);
+    long long best_key = total_key(dot(best, dir));
+    for (uint32_t k = 1; k < n; ++k) {
+        const Vec3 x = ld3(verts, k);
+        const long long key = total_key(dot(x, dir));
+        if (best_key <= key) {
+            best_key = key;
+            best = x;
+        }
+    }
+    return best;
+}
+
+// (value, index) reductions.  `width` lanes (32 or 64) starting at aligned groups.
+__device__ __forceinline__ void reduce_max_first(double &v, uint32_t &idx, uint32_t width)
+{
+    for (uint32_t off = width >> 1; off; off >>= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const uint32_t oi = __shfl_xor(idx, off, 64);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+__device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint32_t width)
+{
+    for (uint32_t off = width >> 1; off; off >>= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const uint32_t oi = __shfl_xor(idx, off, 64);
+        if (ov < v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+__device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+__global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t, const uint32_t *__restrict__ pairs,
+                                                  uint32_t n_pairs, Manifold *__restrict__ out)
+{
+    __shared__ PairLds s;
+    const uint32_t p = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (p >= n_pairs)
+        return;
+
+    // ---- wave-uniform inputs -------------------------------------------------------------------
+    const uint32_t ia = pairs[2 * p], ib = pairs[2 * p + 1];
+    const Frame fa = body_frame(b, ia), fb = body_frame(b, ib);
+    const Frame fa_inv = inverse(fa), fb_inv = inverse(fb);
+    const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
+    const ShapeDesc da = t.desc[sa], db = t.desc[sb];
+
+    Manifold *m = out + p;
+    if (da.n_verts == 0 || db.n_verts == 0 || da.n_faces == 0 || db.n_faces == 0) {
+        if (lane == 0)
+            m->n_points = 0; // the reference's .unwrap() / index would panic; the extension reports "no contact"
+        return;
+    }
+
+    // ---- both vertex sets into LDS: world space, and the other body's local space -----------------
+    const uint32_t half = lane >> 5, k = lane & 31u; // lanes 0-31 work for A, 32-63 for B
+    {
+        const ShapeDesc dm = half ? db : da;
+        if (k < dm.n_verts) {
+            const double *v = t.verts + 3 * (size_t)(dm.vert0 + k);
+            const Vec3 w = (half ? fb : fa) * Vec3{v[0], v[1], v[2]};
+            st3(s.world[half], k, w);
+            st3(s.local[half], k, (half ? fa_inv : fb_inv) * w); // frames.0.inverse() * (frames.1 * p), :136-137
+        }
+    }
+    __syncthreads();
+
+    // ---- face queries (src/collision.rs:123-149), A's faces on lanes 0-31, B's on lanes 32-63 -----
+    double fdist = -DBL_MAX;
+    uint32_t fidx = kNone;
+    {
+        const ShapeDesc dm = half ? db : da;
+        const uint32_t n_other = half ? da.n_verts : db.n_verts;
+        if (k < dm.n_faces) {
+            const double *pl = t.planes + 4 * (size_t)(dm.face0 + k);
+            const Vec3 n{pl[0], pl[1], pl[2]};
+            const Vec3 sup = support_last_max(s.local[half ^ 1u], n_other, -n);
+            const double dist = dot(n, sup) - pl[3];
+            if (dist > -DBL_MAX) { // a NaN distance never beats f64::MIN, as `distance > max_distance`
+                fdist = dist;
+                fidx = k;
+            }
+        }
+    }
+    reduce_max_first(fdist, fidx, 32);
+    const double qa = __shfl(fdist, 0, 64), qb = __shfl(fdist, 32, 64);
+    const uint32_t face_a = __shfl(fidx, 0, 64), face_b = __shfl(fidx, 32, 64);
+    if (qa >= 0.0 || qb >= 0.0 || face_a == kNone || face_b == kNone) {
+        if (lane == 0)
+            m->n_points = 0;
+        return;
+    }
+
+    // ---- edge query (src/collision.rs:151-197): E_A x E_B pairs strided over the 64 lanes ---------
+    double ebest = -DBL_MAX;
+    uint32_t eq = kNone;
+    {
+        const double *cc = t.centroids + 3 * (size_t)sa;
+        const Vec3 centroid_a = fa * Vec3{cc[0], cc[1], cc[2]};
+        const uint32_t total = da.n_edges * db.n_edges;
+        for (uint32_t q = lane; q < total; q += 64) {
+            const uint32_t i = q / db.n_edges, j = q - i * db.n_edges;
+            const uint32_t *ea = t.edges + 2 * (size_t)(da.edge0 + i), *eb = t.edges + 2 * (size_t)(db.edge0 + j);
+            const Vec3 foot = ld3(s.world[0], ea[0]);
+            const Vec3 e0 = ld3(s.world[0], ea[1]) - foot;
+            const Vec3 b0 = ld3(s.world[1], eb[0]);
+            const Vec3 e1 = ld3(s.world[1], eb[1]) - b0;
+            Vec3 axis = normalized(cross(e0, e1));
+            if (!finite3(axis))
+                continue; // parallel (NaN) or degenerate axis: every comparison below is false in the reference too
+            if (dot(axis, foot - centroid_a) < 0.0)
+                axis = -axis;
+            // "Ignore if another point on `a` is further in the direction to `b`" -- with a tolerance
+            // (the edge's own second endpoint beats the foot by rounding noise otherwise) ...
+            double reach = dot(ld3(s.world[0], 0), axis);
+            for (uint32_t v = 1; v < da.n_verts; ++v) {
+                const double r = dot(ld3(s.world[0], v), axis);
+                if (r > reach)
+                    reach = r;
+            }
+            if (reach > dot(foot, axis) + kSupportTol)
+                continue;
+            // ... and mirrored for B, so that both edges are supporting features (extension rule).
+            const Vec3 nax = -axis;
+            Vec3 sup = ld3(s.world[1], 0);
+            double breach = dot(sup, nax);
+            for (uint32_t v = 1; v < db.n_verts; ++v) {
+                const Vec3 x = ld3(s.world[1], v);
+                const double r = dot(x, nax);
+                if (r >= breach) { // last maximum, as Polytope::support
+                    breach = r;
+                    sup = x;
+                }
+            }
+            if (breach > dot(b0, nax) + kSupportTol)
+                continue;
+            const Plane pl = plane_from_point_normal(foot, axis);
+            const double dist = distance(pl, sup);
+            if (dist > ebest) { // ascending q on this lane: first maximum
+                ebest = dist;
+                eq = q;
+            }
+        }
+    }
+    reduce_max_first(ebest, eq, 64);
+    if (ebest >= 0.0) {
+        if (lane == 0)
+            m->n_points = 0;
+        return;
+    }
+
+    // ---- feature choice (src/collision.rs:57-59, 89-92 as comments; kEdgeBias is this extension's) --
+    const double face_best = qa > qb ? qa : qb;
+    const bool use_edges = eq != kNone && ebest > face_best + kEdgeBias;
+
+    if (use_edges) {
+        if (lane == 0) {
+            const uint32_t i = eq / db.n_edges, j = eq - i * db.n_edges;
+            const uint32_t *ea = t.edges + 2 * (size_t)(da.edge0 + i), *eb = t.edges + 2 * (size_t)(db.edge0 + j);
+            const Vec3 a0 = ld3(s.world[0], ea[0]), a1 = ld3(s.world[0], ea[1]);
+            const Vec3 b0 = ld3(s.world[1], eb[0]), b1 = ld3(s.world[1], eb[1]);
+            const Vec3 d1 = a1 - a0, d2 = b1 - b0, r = a0 - b0;
+            const double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), bb = dot(d1, d2);
+            const double denom = a * e - bb * bb;
+            double sp = clamp01((bb * f - c * e) / denom);
+            double tp = (bb * sp + f) / e;
+            if (tp < 0.0) {
+                tp = 0.0;
+                sp = clamp01(-c / a);
+            } else if (tp > 1.0) {
+                tp = 1.0;
+                sp = clamp01((bb - c) / a);
+            }
+            const Vec3 pa = a0 + d1 * sp, pb = b0 + d2 * tp;
+            m->n_points = 1;
+            m->feature = 2;
+            m->index_a = i;
+            m->index_b = j;
+            m->separation = ebest;
+            m->p_ref[0][0] = pa.x, m->p_ref[0][1] = pa.y, m->p_ref[0][2] = pa.z;
+            m->p_inc[0][0] = pb.x, m->p_inc[0][1] = pb.y, m->p_inc[0][2] = pb.z;
+        }
+        return;
+    }
+
+    // ---- face contact: reference body R (A if qa is the maximum, else B), incident body I ----------
+    const uint32_t r = (qa == face_best) ? 0u : 1u; // index into s.world: 0 = A, 1 = B
+    const uint32_t ref_face = r ? face_b : face_a;
+    const Frame fr = r ? fb : fa, fi = r ? fa : fb;
+    const ShapeDesc dr = r ? db : da, di = r ? da : db;
+    const double *rp = t.planes + 4 * (size_t)(dr.face0 + ref_face);
+    const Plane ref_plane = fr * Plane{Vec3{rp[0], rp[1], rp[2]}, rp[3]}; // frames.0 * polytopes.0.plane(face), :66
+
+    // incident face: least normal . ref_normal, first minimum (:76-85); one face per lane
+    double idot = DBL_MAX;
+    uint32_t iface = kNone;
+    if (lane < di.n_faces) {
+        const double *pl = t.planes + 4 * (size_t)(di.face0 + lane);
+        const Plane w = fi * Plane{Vec3{pl[0], pl[1], pl[2]}, pl[3]};
+        const double d = dot(w.normal, ref_plane.normal);
+        if (d < DBL_MAX) {
+            idot = d;
+            iface = lane;
+        }
+    }
+    reduce_min_first(idot, iface, 64);
+    if (iface == kNone)
+        iface = 0;
+
+    if (lane != 0)
+        return;
+
+    // Sutherland-Hodgman on lane 0: incident polygon clipped by the side planes of the reference face.
+    const uint32_t *rv = t.face_verts + t.face_start[dr.face0 + ref_face];
+    const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
+    const uint32_t *iv = t.face_verts + t.face_start[di.face0 + iface];
+    uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
+    for (uint32_t q = 0; q < np; ++q)
+        st3(s.poly[0], q, ld3(s.world[r ^ 1u], iv[q]));
+    uint32_t cur = 0;
+    for (uint32_t e = 0; e < nr && np > 0; ++e) {
+        const Vec3 a = ld3(s.world[r], rv[e]), bnext = ld3(s.world[r], rv[(e + 1) % nr]);
+        const Vec3 c = ld3(s.world[r], rv[(e + 2) % nr]);
+        Vec3 side = cross(bnext - a, ref_plane.normal);
+        if (dot(side, c - a) > 0.0)
+            side = -side;
+        uint32_t nd = 0;
+        for (uint32_t q = 0; q < np; ++q) {
+            const Vec3 p0 = ld3(s.poly[cur], q), p1 = ld3(s.poly[cur], (q + 1) % np);
+            const double d0 = dot(side, p0 - a), d1 = dot(side, p1 - a);
+            const bool in0 = d0 <= 0.0, in1 = d1 <= 0.0;
+            if (in0 && nd < 16)
+                st3(s.poly[cur ^ 1u], nd++, p0);
+            if (in0 != in1 && nd < 16)
+                st3(s.poly[cur ^ 1u], nd++, p0 + (p1 - p0) * (d0 / (d0 - d1)));
+        }
+        np = nd;
+        cur ^= 1u;
+    }
+    uint32_t n_out = 0;
+    for (uint32_t q = 0; q < np && n_out < kMaxManifoldPoints; ++q) {
+        const Vec3 pt = ld3(s.poly[cur], q);
+        const double d = distance(ref_plane, pt);
+        if (d >= 0.0)
+            continue;
+        const Vec3 on_ref = pt - d * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
+        m->p_inc[n_out][0] = pt.x, m->p_inc[n_out][1] = pt.y, m->p_inc[n_out][2] = pt.z;
+        m->p_ref[n_out][0] = on_ref.x, m->p_ref[n_out][1] = on_ref.y, m->p_ref[n_out][2] = on_ref.z;
+        ++n_out;
+    }
+    m->n_points = n_out;
+    m->feature = r;
+    m->index_a = r ? iface : face_a;
+    m->index_b = r ? face_b : iface;
+    m->separation = face_best;
+}
+
+} // namespace
+
+hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const uint32_t *pairs, uint32_t n_pairs,
+                            Manifold *out, hipStream_t stream)
+{
+    if (n_pairs)
+        hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, pairs, n_pairs, out);
+    return hipGetLastError();
+}
+
+} // namespace xpbd

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include "xpbd_kernels.h"
+#include "xpbd_math.hpp"
+#include "xpbd_pairs.h"
 
 namespace {
 
@@ -93,6 +95,16 @@ struct xpbd_world {
     DeviceBuffer shape_verts, shape_offsets;
     uint32_t n_shapes = 0, total_verts = 0;
     std::vector<uint32_t> host_offsets;
+
+    // extension: polytope topology for the body-body narrowphase
+    DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
+    bool has_topology = false;
+    xpbd::PolytopeTables tables() const
+    {
+        return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
+                                    shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
+                                    face_verts.as<uint32_t>(), edges.as<uint32_t>(), n_shapes};
+    }
 
     xpbd::BodyArrays arrays() const
     {
@@ -199,7 +211,9 @@ void xpbd_world_destroy(xpbd_world *w)
     if (w->stream)
         (void)hipStreamSynchronize(w->stream);
     for (DeviceBuffer *b : {&w->dyn, &w->stat, &w->shape_id, &w->aos_staging, &w->last_mask, &w->trace,
-                            &w->block_counts, &w->contacts, &w->shape_verts, &w->shape_offsets})
+                            &w->block_counts, &w->contacts, &w->shape_verts, &w->shape_offsets, &w->planes,
+                            &w->centroids, &w->shape_desc, &w->face_start, &w->face_verts, &w->edges, &w->pair_buf,
+                            &w->manifold_buf})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
@@ -235,6 +249,112 @@ int xpbd_world_set_shapes(xpbd_world *w, const double *verts_xyz, const uint32_t
     w->n_shapes = n_shapes;
     w->total_verts = total;
     w->host_offsets.assign(vert_offsets, vert_offsets + n_shapes + 1);
+    w->has_topology = false;
+    return XPBD_OK;
+}
+
+int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_t n_shapes)
+{
+    if (!w || !shapes || n_shapes == 0)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: NULL argument or no shapes");
+    std::vector<double> verts, planes, centroids;
+    std::vector<uint32_t> vert_offsets{0}, face_start{0}, face_verts, edges;
+    std::vector<xpbd::ShapeDesc> desc;
+    for (uint32_t s = 0; s < n_shapes; ++s) {
+        const xpbd_polytope &p = shapes[s];
+        if ((p.n_vertices && !p.vertices_xyz) || (p.n_edges && !p.edges) ||
+            (p.n_faces && (!p.face_offsets || !p.face_indices)))
+            return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: shape %u has a NULL table", s);
+        if (p.n_vertices > XPBD_MAX_SHAPE_VERTS || p.n_faces > 64 || p.n_edges > 4096)
+            return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: shape %u too large (%u vertices, %u faces, %u edges)",
+                        s, p.n_vertices, p.n_faces, p.n_edges);
+        xpbd::ShapeDesc d{};
+        d.vert0 = (uint32_t)(verts.size() / 3);
+        d.n_verts = p.n_vertices;
+        d.face0 = (uint32_t)(planes.size() / 4);
+        d.n_faces = p.n_faces;
+        d.edge0 = (uint32_t)(edges.size() / 2);
+        d.n_edges = p.n_edges;
+        verts.insert(verts.end(), p.vertices_xyz, p.vertices_xyz + 3 * (size_t)p.n_vertices);
+        vert_offsets.push_back((uint32_t)(verts.size() / 3));
+        auto vertex = [&](uint32_t i) {
+            return xpbd::Vec3{p.vertices_xyz[3 * i], p.vertices_xyz[3 * i + 1], p.vertices_xyz[3 * i + 2]};
+        };
+        for (uint32_t e = 0; e < 2 * p.n_edges; ++e) {
+            if (p.edges[e] >= p.n_vertices)
+                return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: shape %u edge vertex out of range", s);
+            edges.push_back(p.edges[e]);
+        }
+        const xpbd::Vec3 centroid{p.centroid[0], p.centroid[1], p.centroid[2]};
+        for (uint32_t f = 0; f < p.n_faces; ++f) {
+            const uint32_t f0 = p.face_offsets[f], f1 = p.face_offsets[f + 1];
+            if (f1 < f0 || f1 - f0 < 3 || f1 - f0 > xpbd::kMaxFaceVerts)
+                return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: shape %u face %u needs 3..%u vertices", s, f,
+                            xpbd::kMaxFaceVerts);
+            for (uint32_t q = f0; q < f1; ++q) {
+                if (p.face_indices[q] >= p.n_vertices)
+                    return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: shape %u face vertex out of range", s);
+                face_verts.push_back(p.face_indices[q]);
+            }
+            face_start.push_back((uint32_t)face_verts.size());
+            // Polytope::plane (src/geometry.rs:262-271) over Plane::from_points / facing / flip (:16-24, :55-68)
+            const xpbd::Vec3 p0 = vertex(p.face_indices[f0]), p1 = vertex(p.face_indices[f0 + 1]),
+                             p2 = vertex(p.face_indices[f0 + 2]);
+            xpbd::Vec3 n = xpbd::normalized(xpbd::cross(p1 - p0, p2 - p0));
+            double disp = xpbd::dot(n, p0);
+            const bool facing = xpbd::dot(n, centroid - disp * n) >= 0.0;
+            if (facing) {
+                n = -n;
+                disp = -disp;
+            }
+            planes.insert(planes.end(), {n.x, n.y, n.z, disp});
+        }
+        centroids.insert(centroids.end(), {centroid.x, centroid.y, centroid.z});
+        desc.push_back(d);
+    }
+    static const double zero3[3] = {0, 0, 0};
+    if (int rc = xpbd_world_set_shapes(w, verts.empty() ? zero3 : verts.data(), vert_offsets.data(), n_shapes))
+        return rc;
+    auto upload = [&](DeviceBuffer &buf, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = buf.reserve(bytes ? bytes : 8);
+        if (e == hipSuccess && bytes)
+            e = hipMemcpy(buf.ptr, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    XPBD_HIP_TRY(upload(w->planes, planes.data(), planes.size() * 8));
+    XPBD_HIP_TRY(upload(w->centroids, centroids.data(), centroids.size() * 8));
+    XPBD_HIP_TRY(upload(w->shape_desc, desc.data(), desc.size() * sizeof(xpbd::ShapeDesc)));
+    XPBD_HIP_TRY(upload(w->face_start, face_start.data(), face_start.size() * 4));
+    XPBD_HIP_TRY(upload(w->face_verts, face_verts.data(), face_verts.size() * 4));
+    XPBD_HIP_TRY(upload(w->edges, edges.data(), edges.size() * 4));
+    w->has_topology = true;
+    return XPBD_OK;
+}
+
+int xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_manifold *out)
+{
+    static_assert(sizeof(xpbd_manifold) == sizeof(xpbd::Manifold), "xpbd_manifold must mirror xpbd::Manifold");
+    if (!w || (n_pairs && (!pairs || !out)))
+        return fail(XPBD_E_INVALID, "xpbd_world_narrowphase: NULL argument");
+    if (!w->has_topology)
+        return fail(XPBD_E_INVALID, "xpbd_world_narrowphase: call xpbd_world_set_polytopes first");
+    for (uint32_t k = 0; k < 2 * n_pairs; ++k)
+        if (pairs[k] >= w->n)
+            return fail(XPBD_E_INVALID, "xpbd_world_narrowphase: pair %u names body %u of %u", k / 2, pairs[k], w->n);
+    if (n_pairs == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    XPBD_HIP_TRY(w->pair_buf.reserve((size_t)n_pairs * 8));
+    XPBD_HIP_TRY(w->manifold_buf.reserve((size_t)n_pairs * sizeof(xpbd::Manifold)));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemsetAsync(w->manifold_buf.ptr, 0, (size_t)n_pairs * sizeof(xpbd::Manifold), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->pair_buf.as<uint32_t>(), n_pairs,
+                                        w->manifold_buf.as<xpbd::Manifold>(), w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::Manifold),
+                                hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     return XPBD_OK;
 }
 

@@ -124,4 +124,40 @@ int xpbdh_shape_plane(uint32_t code, double scale, uint32_t face, double out[4])
     return (int)p.faces.size();
 }
 
+// Full topology of a standard shape for xpbd_world_set_polytopes.  counts = {n_vertices, n_edges,
+// n_faces, n_face_indices}; pass NULL arrays to query the counts only.
+void xpbdh_polytope_arrays(uint32_t code, double scale, uint32_t counts[4], double *verts_xyz, uint32_t *edges,
+                           uint32_t *face_offsets, uint32_t *face_indices, double centroid[3])
+{
+    const geometry::Polytope p = shape_by_code(code, scale);
+    uint32_t nfi = 0;
+    for (const auto &f : p.faces)
+        nfi += (uint32_t)f.size();
+    counts[0] = (uint32_t)p.vertices.size();
+    counts[1] = (uint32_t)p.edges.size();
+    counts[2] = (uint32_t)p.faces.size();
+    counts[3] = nfi;
+    if (!verts_xyz)
+        return;
+    for (size_t i = 0; i < p.vertices.size(); ++i) {
+        verts_xyz[3 * i] = p.vertices[i].x;
+        verts_xyz[3 * i + 1] = p.vertices[i].y;
+        verts_xyz[3 * i + 2] = p.vertices[i].z;
+    }
+    for (size_t i = 0; i < p.edges.size(); ++i) {
+        edges[2 * i] = p.edges[i][0];
+        edges[2 * i + 1] = p.edges[i][1];
+    }
+    uint32_t at = 0;
+    face_offsets[0] = 0;
+    for (size_t f = 0; f < p.faces.size(); ++f) {
+        for (uint32_t v : p.faces[f])
+            face_indices[at++] = v;
+        face_offsets[f + 1] = at;
+    }
+    centroid[0] = p.centroid.x;
+    centroid[1] = p.centroid.y;
+    centroid[2] = p.centroid.z;
+}
+
 } // extern "C"

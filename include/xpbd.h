@@ -142,6 +142,53 @@ int  xpbd_world_set_mode(xpbd_world *w, uint32_t mode);
 int  xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts,
                    double dt, uint32_t substeps);
 
+/* ---------------------------------------------------------------------------
+ * EXTENSION -- body-body contacts.  NOT in the reference:
+ * its `sat` (src/collision.rs:37-121) is an uncalled stub and `World` holds two
+ * bodies that never interact.  These entry points finish that sketch; parity
+ * for them is unpinned (own CPU oracle + invariants), and nothing above
+ * changes behaviour when they are not used.
+ * ------------------------------------------------------------------------- */
+
+/* Full convex polytope (reference `Polytope`, src/geometry.rs:82-93): vertices,
+ * edges (vertex index pairs), faces as CSR (face_offsets has n_faces+1 entries
+ * into face_indices) and the centroid.  Faces need 3..8 vertices. */
+typedef struct xpbd_polytope {
+    const double   *vertices_xyz;
+    const uint32_t *edges;
+    const uint32_t *face_offsets;
+    const uint32_t *face_indices;
+    uint32_t n_vertices, n_edges, n_faces, reserved;
+    double   centroid[3];
+} xpbd_polytope;
+
+#define XPBD_MAX_MANIFOLD_POINTS 8u
+#define XPBD_FEATURE_FACE_A 0u  /* reference face on A, incident body B */
+#define XPBD_FEATURE_FACE_B 1u  /* reference face on B, incident body A */
+#define XPBD_FEATURE_EDGES  2u  /* edge of A (reference) against edge of B */
+
+/* Contact manifold of one pair.  p_ref[k] lies on the reference body's surface,
+ * p_inc[k] is the penetrating point of the incident body (world space). */
+typedef struct xpbd_manifold {
+    uint32_t n_points;   /* 0: separated */
+    uint32_t feature;    /* XPBD_FEATURE_* (valid when n_points > 0) */
+    uint32_t index_a;    /* face of A (reference or incident) or edge of A */
+    uint32_t index_b;    /* face of B (incident or reference) or edge of B */
+    double   separation; /* largest separating-axis value, < 0 */
+    double   p_ref[XPBD_MAX_MANIFOLD_POINTS][3];
+    double   p_inc[XPBD_MAX_MANIFOLD_POINTS][3];
+} xpbd_manifold;
+
+/* Replaces xpbd_world_set_shapes when body-body contacts are wanted: sets the
+ * vertex tables AND the face/edge topology (outward face planes are derived as
+ * Polytope::plane does, src/geometry.rs:262-271). */
+int  xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_t n_shapes);
+
+/* SAT narrowphase of the given body pairs (pairs[2k], pairs[2k+1] = A, B) at the
+ * world's current poses: one wave per pair.  out has n_pairs entries. */
+int  xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs,
+                            xpbd_manifold *out);
+
 /* Diagnostics: quotient[i] = a[i] / b[i], root[i] = sqrt(a[i]) computed on the
  * device with the stepper's own code generation.  Bit-exact contact lists need
  * both to be correctly rounded; the parity tests check this against the host. */

@@ -177,3 +177,28 @@ def masks_to_contacts(mask_row):
             m >>= 1
             v += 1
     return np.array(out, dtype=np.uint32).reshape(-1, 2)
+
+
+# ---- body-body contact extension (oracle/xpbd_pairs_oracle.c; parity unpinned) -----------------
+class Manifold(C.Structure):
+    _fields_ = [("separated", C.c_int32), ("feature", C.c_int32), ("index_a", C.c_uint32), ("index_b", C.c_uint32),
+                ("separation", C.c_double), ("query", C.c_double * 3), ("n_points", C.c_uint32),
+                ("p_ref", Vec3 * 8), ("p_inc", Vec3 * 8)]
+
+    def points(self):
+        return (np.array([self.p_ref[i].np() for i in range(self.n_points)]).reshape(-1, 3),
+                np.array([self.p_inc[i].np() for i in range(self.n_points)]).reshape(-1, 3))
+
+
+FEATURE_FACE_A, FEATURE_FACE_B, FEATURE_EDGES = 0, 1, 2
+
+
+def sat(fa, fb, pa, pb):
+    """op_sat for two (position[3], rotation[4]) frames and two Polytope objects."""
+    L = load()
+    if not hasattr(L, "_sat_ready"):
+        L.op_sat.restype, L.op_sat.argtypes = None, [Frame, Frame, C.POINTER(Polytope), C.POINTER(Polytope), C.POINTER(Manifold)]
+        L._sat_ready = True
+    m = Manifold()
+    L.op_sat(frame(*fa), frame(*fb), C.byref(pa), C.byref(pb), C.byref(m))
+    return m
