@@ -17,6 +17,7 @@ BYTES_PER_BODY_SUBSTEP = 412  # read 13+25 doubles + 4 B shape id, wr
 
 MODE_FUSED = 0
 MODE_PER_SUBSTEP = 1
+MODE_CONTACTS = 2  # extension: ground + body-body contacts
 FLAG_TRACE_CONTACTS = 1
 
 OK, E_INVALID, E_HIP, E_OOM, E_SINGULAR_INERTIA, E_NO_DEVICE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
@@ -35,6 +36,8 @@ ABI_SYMBOLS = [
     "xpbd_world_body_count", "xpbd_world_step", "xpbd_world_synchronize", "xpbd_world_download_contacts",
     "xpbd_world_download_contact_masks", "xpbd_world_set_stream", "xpbd_world_get_stream", "xpbd_world_set_mode",
     "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
+    "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
+    "xpbd_world_download_neighbours",
 ]
 
 
@@ -108,6 +111,10 @@ def hip_lib():
         L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
         L.xpbd_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
         L.xpbd_world_narrowphase.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_set_contact_pad.argtypes = [C.c_void_p, C.c_double]
+        L.xpbd_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.xpbd_world_build_neighbours.argtypes = [C.c_void_p, C.c_double, _u32p]
+        L.xpbd_world_download_neighbours.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint32]
         _hip = L
     return _hip
 
@@ -233,6 +240,24 @@ class World:
         out = np.zeros(pr.shape[0], dtype=MANIFOLD_DTYPE)
         _check(hip_lib().xpbd_world_narrowphase(self._h, _u32(pr), pr.shape[0], out.ctypes.data))
         return out
+
+    def set_contact_pad(self, pad):
+        _check(hip_lib().xpbd_world_set_contact_pad(self._h, pad))
+
+    def contact_stats(self):
+        """(neighbour pairs of the last step, touching pairs, manifold points) -- the last two since the previous call."""
+        out = (C.c_uint64 * 3)()
+        _check(hip_lib().xpbd_world_contact_stats(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def neighbours(self, dt):
+        """Runs the sphere broadphase as step(dt, .) would: (offsets[n+1], neighbours) CSR, ascending."""
+        n_entries = C.c_uint32(0)
+        _check(hip_lib().xpbd_world_build_neighbours(self._h, dt, C.byref(n_entries)))
+        off = np.zeros(self.n + 1, dtype=np.uint32)
+        nb = np.zeros(max(n_entries.value, 1), dtype=np.uint32)
+        _check(hip_lib().xpbd_world_download_neighbours(self._h, _u32(off), _u32(nb), nb.size))
+        return off, nb[: n_entries.value]
 
     def set_stream(self, stream_ptr):
         _check(hip_lib().xpbd_world_set_stream(self._h, C.c_void_p(stream_ptr)))

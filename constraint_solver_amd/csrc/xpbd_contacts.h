@@ -1,0 +1,63 @@
+// xpbd_contacts.h -- body-body contact EXTENSION: broadphase + per-substep contact pipeline.
+// Semantics are defined by oracle/xpbd_pairs_oracle.h (op_contacts_step); parity unpinned.
+#pragma once
+
+#include "xpbd_pairs.h"
+
+namespace xpbd {
+
+// Device buffers of the contact pipeline (owned by the world, sized by the host).
+struct ContactBuffers {
+    // broadphase, per body
+    double *centers;        // [3][stride] bounding-sphere centre (frame * centroid)
+    double *radius;         // [stride]    r_shape + |v| dt + pad
+    int32_t *cell;          // [3][stride] grid cell of the centre
+    uint32_t *key;          // [stride]    hash bucket of that cell
+    unsigned long long *max_radius_bits; // [1]
+    // hash table, table_size = power of two
+    uint32_t *bucket_start; // [table_size + 1] counts -> exclusive scan
+    uint32_t *bucket_cursor;// [table_size]
+    uint32_t *items;        // [n] body ids grouped by bucket, ascending inside a bucket
+    uint32_t table_size;
+    // neighbour lists (CSR, ascending) and the pair list i < j
+    uint32_t *nbr_off;      // [n + 1]
+    uint32_t *pair_first;   // [n + 1]
+    uint32_t *upper_start;  // [n]  index in nbr of b's first neighbour > b
+    uint32_t *nbr;          // [entries]
+    uint32_t *nbr_pair;     // [entries] pair index of (min, max)
+    uint32_t *pairs;        // [n_pairs][2]
+    // per substep
+    double *frame_p1;       // [7][stride] post-integrate frame: origin xyz, rotation s x y z
+    double *frame_past;     // [7][stride] frame before integrate
+    double *past_pos;       // [3][stride] position before integrate (for derive)
+    Manifold *manifolds;    // [n_pairs]
+    unsigned long long *stats; // [2] touching pairs, manifold points (summed over substeps)
+    uint32_t *scan_scratch; // block totals of the scans
+};
+
+// ---- broadphase (once per step call) -------------------------------------------------------------
+hipError_t launch_bounds_and_cells(const BodyArrays &b, const PolytopeTables &t, const double *shape_radius,
+                                   double dt, double pad, const ContactBuffers &c, hipStream_t stream);
+hipError_t launch_build_buckets(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream);
+// counts into nbr_off / pair_first (then scanned in place; totals at [n])
+hipError_t launch_neighbour_count(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream);
+hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream);
+
+// ---- per substep -----------------------------------------------------------------------------------
+// integrate + remember frames + ground contacts (sequential per body), pose' written back to b.dyn
+hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
+                                   uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream);
+// SAT of every neighbour pair on the post-integrate frames
+hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
+                                    uint32_t n_pairs, hipStream_t stream);
+// Jacobi pair solve (reads b.dyn = pose', writes dyn_out) + derive
+hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
+                                    hipStream_t stream);
+
+// Frames of all bodies from the SoA state into a [7][stride] array (used by the diagnostic narrowphase).
+hipError_t launch_body_frames(const BodyArrays &b, double *frames, hipStream_t stream);
+
+// Exclusive scan of data[0..n) in place; data[n] receives the total.  scratch: >= n/1024 + 2 uint32.
+hipError_t launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *scratch, hipStream_t stream);
+
+} // namespace xpbd

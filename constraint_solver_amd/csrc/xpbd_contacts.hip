@@ -1,0 +1,535 @@
+// xpbd_contacts.hip -- body-body contact EXTENSION for gfx950: sphere broadphase on a hashed
+// uniform grid and the per-substep contact pipeline
+//     integrate + ground contacts  ->  wave-per-pair SAT  ->  Jacobi pair solve + derive.
+// Semantics are defined by oracle/xpbd_pairs_oracle.h (op_contacts_step); the reference has no
+// body-body contacts, so parity is UNPINNED.  The ground-contact part reuses the reference path
+// (xpbd_step.hpp) unchanged.
+//
+// Determinism: every floating-point sum is formed by ONE lane in a fixed order (neighbour index,
+// then manifold point index); atomics are used on integers only (bucket counts, cursors, stats)
+// and every order they leave open is removed by a sort.  Results do not depend on launch order,
+// on the hash-table size or on how the world is sharded.
+#include <cfloat>
+
+#include "xpbd_contacts.h"
+#include "xpbd_step.hpp"
+
+namespace xpbd {
+namespace {
+
+constexpr uint32_t kBlock = 256;
+
+__device__ __forceinline__ uint32_t cell_hash(int32_t x, int32_t y, int32_t z)
+{
+    return ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349663u) ^ ((uint32_t)z * 83492791u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Exclusive scan of uint32 (three small kernels; 1024 elements per block).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_scan_exclusive(uint32_t v, uint32_t *total)
+{
+    __shared__ uint32_t wave_sum[kBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if (lane >= d)
+            inc += up;
+    }
+    if (lane == 63)
+        wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kBlock / 64; ++k) {
+        const uint32_t ws = wave_sum[k];
+        if (k < wave)
+            before += ws;
+        all += ws;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ void k_scan_blocks(uint32_t *__restrict__ data, uint32_t n, uint32_t *__restrict__ block_totals)
+{
+    const uint32_t base = blockIdx.x * (kBlock * 4) + threadIdx.x * 4;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        v[k] = base + k < n ? data[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_scan_exclusive(sum, &total);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (base + k < n)
+            data[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0)
+        block_totals[blockIdx.x] = total;
+}
+
+__global__ void k_scan_totals(uint32_t *__restrict__ block_totals, uint32_t nb)
+{
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += kBlock) {
+        const uint32_t k = base + threadIdx.x;
+        const uint32_t v = k < nb ? block_totals[k] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan_exclusive(v, &total);
+        const uint32_t carry = carry_s;
+        if (k < nb)
+            block_totals[k] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        block_totals[nb] = carry_s;
+}
+
+__global__ void k_scan_add(uint32_t *__restrict__ data, uint32_t n, const uint32_t *__restrict__ block_totals, uint32_t nb)
+{
+    const uint32_t base = blockIdx.x * (kBlock * 4) + threadIdx.x * 4;
+    const uint32_t add = block_totals[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (base + k < n)
+            data[base + k] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        data[n] = block_totals[nb];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Broadphase
+// ---------------------------------------------------------------------------------------------------
+// Bounding sphere of every body: centre = frame * centroid, radius = r_shape + |v| dt + pad.
+__global__ void k_bounds(BodyArrays b, PolytopeTables t, const double *__restrict__ shape_radius, double dt, double pad,
+                         ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t sid = b.shape_id[i];
+    const double *cc = t.centroids + 3 * (size_t)sid;
+    const Vec3 centre = body_frame(b, i) * Vec3{cc[0], cc[1], cc[2]};
+    const Vec3 vel = load3(b.dyn, D_VEL, b.stride, i);
+    const double r = shape_radius[sid] + length(vel) * dt + pad;
+    store3(c.centers, 0, b.stride, i, centre);
+    c.radius[i] = r;
+    if (r > 0.0 && r <= DBL_MAX) // positive finite doubles order like their bit patterns
+        atomicMax(c.max_radius_bits, (unsigned long long)__double_as_longlong(r));
+}
+
+// Grid cell (edge = 2 * largest radius, so overlapping spheres sit in adjacent cells) and bucket count.
+__global__ void k_cells(BodyArrays b, ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const double edge = 2.0 * __longlong_as_double((long long)*c.max_radius_bits);
+    const Vec3 centre = load3(c.centers, 0, b.stride, i);
+    int32_t cell[3];
+    const double coord[3] = {centre.x, centre.y, centre.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double q = edge > 0.0 ? floor(coord[a] / edge) : 0.0;
+        if (!(q >= -1.0e9))   // NaN or far negative
+            q = -1.0e9;
+        if (q > 1.0e9)
+            q = 1.0e9;
+        cell[a] = (int32_t)q;
+        c.cell[(size_t)a * b.stride + i] = cell[a];
+    }
+    const uint32_t key = cell_hash(cell[0], cell[1], cell[2]) & (c.table_size - 1);
+    c.key[i] = key;
+    atomicAdd(&c.bucket_start[key], 1u);
+}
+
+__global__ void k_scatter(BodyArrays b, ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t key = c.key[i];
+    c.items[c.bucket_start[key] + atomicAdd(&c.bucket_cursor[key], 1u)] = i;
+}
+
+// The scatter order inside a bucket depends on timing: sort every bucket (a handful of ids).
+__global__ void k_sort_buckets(ContactBuffers c)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c.table_size)
+        return;
+    const uint32_t lo = c.bucket_start[k], hi = c.bucket_start[k + 1];
+    for (uint32_t a = lo + 1; a < hi; ++a) {
+        const uint32_t v = c.items[a];
+        uint32_t p = a;
+        while (p > lo && c.items[p - 1] > v) {
+            c.items[p] = c.items[p - 1];
+            --p;
+        }
+        c.items[p] = v;
+    }
+}
+
+// Calls visit(j) for every body j != i whose sphere overlaps body i's, each exactly once.
+template <class Visit>
+__device__ __forceinline__ void for_each_neighbour(const BodyArrays &b, const ContactBuffers &c, uint32_t i, Visit visit)
+{
+    const Vec3 ci = load3(c.centers, 0, b.stride, i);
+    const double ri = c.radius[i];
+    const int32_t cx = c.cell[i], cy = c.cell[(size_t)b.stride + i], cz = c.cell[(size_t)2 * b.stride + i];
+    for (int32_t dz = -1; dz <= 1; ++dz)
+        for (int32_t dy = -1; dy <= 1; ++dy)
+            for (int32_t dx = -1; dx <= 1; ++dx) {
+                const int32_t nx = cx + dx, ny = cy + dy, nz = cz + dz;
+                const uint32_t key = cell_hash(nx, ny, nz) & (c.table_size - 1);
+                const uint32_t lo = c.bucket_start[key], hi = c.bucket_start[key + 1];
+                for (uint32_t s = lo; s < hi; ++s) {
+                    const uint32_t j = c.items[s];
+                    if (j == i)
+                        continue;
+                    // several cells can share a bucket: take j only from the cell being visited
+                    if (c.cell[j] != nx || c.cell[(size_t)b.stride + j] != ny || c.cell[(size_t)2 * b.stride + j] != nz)
+                        continue;
+                    const Vec3 d = ci - load3(c.centers, 0, b.stride, j);
+                    const double reach = ri + c.radius[j];
+                    if (dot(d, d) < reach * reach)
+                        visit(j);
+                }
+            }
+}
+
+__global__ void k_neighbour_count(BodyArrays b, ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    uint32_t all = 0, upper = 0;
+    for_each_neighbour(b, c, i, [&](uint32_t j) {
+        ++all;
+        upper += j > i;
+    });
+    c.nbr_off[i] = all;
+    c.pair_first[i] = upper;
+}
+
+// Neighbour list of every body, ascending (insertion sort while filling; lists are short), the
+// pair list i < j in (i, j) order, and for every list entry the index of its pair.
+__global__ void k_neighbour_fill(BodyArrays b, ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t lo = c.nbr_off[i];
+    uint32_t count = 0;
+    for_each_neighbour(b, c, i, [&](uint32_t j) {
+        uint32_t p = lo + count;
+        while (p > lo && c.nbr[p - 1] > j) {
+            c.nbr[p] = c.nbr[p - 1];
+            --p;
+        }
+        c.nbr[p] = j;
+        ++count;
+    });
+    uint32_t below = 0;
+    while (below < count && c.nbr[lo + below] < i)
+        ++below;
+    c.upper_start[i] = lo + below;
+    const uint32_t first = c.pair_first[i];
+    for (uint32_t k = below; k < count; ++k) {
+        c.pairs[2 * (size_t)(first + k - below)] = i;
+        c.pairs[2 * (size_t)(first + k - below) + 1] = c.nbr[lo + k];
+    }
+}
+
+__global__ void k_neighbour_pair_index(BodyArrays b, ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    for (uint32_t k = c.nbr_off[i]; k < c.nbr_off[i + 1]; ++k) {
+        const uint32_t j = c.nbr[k];
+        if (j > i) {
+            c.nbr_pair[k] = c.pair_first[i] + (k - c.upper_start[i]);
+        } else {
+            // i sits in the upper part of j's ascending list: binary search
+            uint32_t lo = c.upper_start[j], hi = c.nbr_off[j + 1];
+            while (lo + 1 < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (c.nbr[mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            c.nbr_pair[k] = c.pair_first[j] + (lo - c.upper_start[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per substep, per body: integrate, remember the frames, ground contacts (reference path).
+// ---------------------------------------------------------------------------------------------------
+template <bool TRACE>
+__global__ void __launch_bounds__(kBlock) k_integrate_ground(BodyArrays b, ShapeTable shapes, double h, ContactBuffers c,
+                                                             uint32_t *__restrict__ last_mask,
+                                                             uint32_t *__restrict__ trace_masks, uint32_t trace_row)
+{
+    extern __shared__ double lds[]; // shape vertex tables, as in k_step
+    uint32_t *lds_off = reinterpret_cast<uint32_t *>(lds + 3 * shapes.total_verts);
+    for (uint32_t k = threadIdx.x; k < 3 * shapes.total_verts; k += blockDim.x)
+        lds[k] = shapes.verts[k];
+    for (uint32_t k = threadIdx.x; k <= shapes.n_shapes; k += blockDim.x)
+        lds_off[k] = shapes.offsets[k];
+    __syncthreads();
+
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t st = b.stride;
+    const BodyStatic s = load_static(b, i);
+    BodyDynamic d = load_dynamic(b.dyn, st, i);
+    const uint32_t sid = b.shape_id[i];
+    const uint32_t v0 = lds_off[sid];
+    const double compliance = 1e-6 / (h * h);
+
+    const SubstepFrames f = integrate_body(d, s, h);
+    store_frame(c.frame_past, st, i, f.past);
+    store_frame(c.frame_p1, st, i, f.cur);
+    store3(c.past_pos, 0, st, i, f.past_pos);
+    const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
+
+    // pose after the ground contacts; velocities are rewritten by derive in k_pair_solve_derive
+    store3(b.dyn, D_POS, st, i, d.pos);
+    store_quat(b.dyn, D_ROT, st, i, d.rot);
+    last_mask[i] = mask;
+    if (TRACE)
+        trace_masks[(size_t)trace_row * st + i] = mask;
+}
+
+__global__ void k_body_frames(BodyArrays b, double *__restrict__ frames)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b.n)
+        store_frame(frames, b.stride, i, body_frame(b, i));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per substep, per body: Jacobi over the pair contacts, then derive.
+// ---------------------------------------------------------------------------------------------------
+// What the pair solve needs of a body: pose after the ground contacts, mass properties, and its
+// frames before / after this substep's integration.
+struct PairBody {
+    Vec3 pos;
+    Quat rot;
+    double inv_mass;
+    Mat3 inv_inertia;
+    Vec3 com;
+    Frame p1, past;
+};
+
+__device__ __forceinline__ PairBody load_pair_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i)
+{
+    const uint32_t st = b.stride;
+    PairBody p;
+    p.pos = load3(b.dyn, D_POS, st, i);
+    p.rot = load_quat(b.dyn, D_ROT, st, i);
+    p.inv_mass = b.stat[(size_t)S_INV_MASS * st + i];
+    p.inv_inertia.cx = load3(b.stat, S_INV_INERTIA + 0, st, i);
+    p.inv_inertia.cy = load3(b.stat, S_INV_INERTIA + 3, st, i);
+    p.inv_inertia.cz = load3(b.stat, S_INV_INERTIA + 6, st, i);
+    p.com = load3(b.stat, S_COM, st, i);
+    p.p1 = load_frame(c.frame_p1, st, i);
+    p.past = load_frame(c.frame_past, st, i);
+    return p;
+}
+
+// Frame::delta, src/frame.rs:40-44
+__device__ __forceinline__ Vec3 frame_delta(const Frame &cur, const Frame &past, Vec3 global)
+{
+    const Vec3 local = inverse(cur) * global;
+    return global - past * local;
+}
+
+// Constraint::inverse_resitance for one body, src/constraint.rs:25-32
+__device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Vec3 point, Vec3 dir)
+{
+    const Vec3 angular_impulse = conjugate(p.rot) * cross(point - (p.pos + p.com), dir);
+    return p.inv_mass + dot(p.inv_inertia * angular_impulse, angular_impulse);
+}
+
+__global__ void __launch_bounds__(kBlock) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
+                                                              ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t st = b.stride;
+    const double compliance = 1e-6 / (h * h);
+    const PairBody self = load_pair_body(b, c, i);
+
+    Vec3 dpos{0.0, 0.0, 0.0};
+    Quat drot{0.0, 0.0, 0.0, 0.0};
+    uint32_t count = 0;
+    for (uint32_t k = c.nbr_off[i]; k < c.nbr_off[i + 1]; ++k) {
+        const Manifold *m = c.manifolds + c.nbr_pair[k];
+        const uint32_t n_points = m->n_points;
+        if (n_points == 0)
+            continue;
+        const uint32_t j = c.nbr[k];
+        const PairBody other = load_pair_body(b, c, j);
+        // pair (A, B) = (min, max); the reference body is A unless the reference face is on B
+        const bool self_is_a = i < j;
+        const bool ref_is_a = m->feature != 1u;
+        const bool self_is_inc = self_is_a != ref_is_a;
+        const PairBody &inc = self_is_inc ? self : other;
+        const PairBody &ref = self_is_inc ? other : self;
+        for (uint32_t pt = 0; pt < n_points; ++pt) {
+            const Vec3 p_inc{m->p_inc[pt][0], m->p_inc[pt][1], m->p_inc[pt][2]};
+            const Vec3 p_ref{m->p_ref[pt][0], m->p_ref[pt][1], m->p_ref[pt][2]};
+            const Vec3 correction = p_ref - p_inc;
+            const Vec3 delta_rel = frame_delta(inc.p1, inc.past, p_inc) - frame_delta(ref.p1, ref.past, p_ref);
+            const Vec3 delta_tangential = delta_rel - project_on(delta_rel, correction);
+            const Vec3 c0 = p_inc;
+            const Vec3 c1 = p_ref - 1.0 * delta_tangential;
+            const Vec3 difference = c1 - c0;
+            const double dist = length(difference);
+            const Vec3 dir = difference * (1.0 / dist);
+            const double w = generalized_inverse_mass(inc, c0, dir) + generalized_inverse_mass(ref, p_ref, dir);
+            const double lambda = (dist - 0.0) / (w + compliance);
+
+            const Vec3 point = self_is_inc ? c0 : p_ref;
+            const Vec3 impulse = self_is_inc ? lambda * dir : (-lambda) * dir;
+            dpos = dpos + impulse * self.inv_mass;
+            const Vec3 arm = point - (self.pos + self.com);
+            const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
+            drot = drot + (0.5 * spin) * self.rot;
+            ++count;
+        }
+    }
+
+    BodyDynamic d;
+    d.pos = self.pos;
+    d.rot = self.rot;
+    if (count) {
+        const double cnt = (double)count;
+        d.pos = self.pos + dpos / cnt;
+        d.rot = normalized(self.rot + Quat{drot.s / cnt, drot.x / cnt, drot.y / cnt, drot.z / cnt});
+    }
+    derive_body(d, load3(c.past_pos, 0, st, i), self.past.rotation, h);
+    store_dynamic(dyn_out, st, i, d);
+}
+
+uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------------
+hipError_t launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *scratch, hipStream_t stream)
+{
+    const uint32_t nb = (n + kBlock * 4 - 1) / (kBlock * 4);
+    if (nb == 0) {
+        return hipMemsetAsync(data, 0, sizeof(uint32_t), stream);
+    }
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(kBlock), 0, stream, data, n, scratch);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kBlock), 0, stream, scratch, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kBlock), 0, stream, data, n, scratch, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_bounds_and_cells(const BodyArrays &b, const PolytopeTables &t, const double *shape_radius,
+                                   double dt, double pad, const ContactBuffers &c, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(c.max_radius_bits, 0, sizeof(unsigned long long), stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c.bucket_start, 0, (size_t)(c.table_size + 1) * 4, stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c.bucket_cursor, 0, (size_t)c.table_size * 4, stream);
+    if (e != hipSuccess || b.n == 0)
+        return e;
+    hipLaunchKernelGGL(k_bounds, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, t, shape_radius, dt, pad, c);
+    hipLaunchKernelGGL(k_cells, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_buckets(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream)
+{
+    hipError_t e = launch_exclusive_scan(c.bucket_start, c.table_size, c.scan_scratch, stream);
+    if (e != hipSuccess || b.n == 0)
+        return e;
+    hipLaunchKernelGGL(k_scatter, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_sort_buckets, dim3(blocks_for(c.table_size)), dim3(kBlock), 0, stream, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_neighbour_count(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream)
+{
+    if (b.n)
+        hipLaunchKernelGGL(k_neighbour_count, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = launch_exclusive_scan(c.nbr_off, b.n, c.scan_scratch, stream);
+    if (e == hipSuccess)
+        e = launch_exclusive_scan(c.pair_first, b.n, c.scan_scratch, stream);
+    return e;
+}
+
+hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream)
+{
+    if (b.n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_neighbour_fill, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_neighbour_pair_index, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
+                                   uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream)
+{
+    if (b.n == 0)
+        return hipSuccess;
+    const size_t lds_bytes = (size_t)s.total_verts * 3 * sizeof(double) + (size_t)(s.n_shapes + 1) * sizeof(uint32_t);
+    if (trace_masks)
+        hipLaunchKernelGGL(k_integrate_ground<true>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, h, c,
+                           last_mask, trace_masks, trace_row);
+    else
+        hipLaunchKernelGGL(k_integrate_ground<false>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, h, c,
+                           last_mask, trace_masks, trace_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
+                                    uint32_t n_pairs, hipStream_t stream)
+{
+    return launch_sat_pairs(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, c.stats, stream);
+}
+
+hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
+                                    hipStream_t stream)
+{
+    if (b.n)
+        hipLaunchKernelGGL(k_pair_solve_derive, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_body_frames(const BodyArrays &b, double *frames, hipStream_t stream)
+{
+    if (b.n)
+        hipLaunchKernelGGL(k_body_frames, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, frames);
+    return hipGetLastError();
+}
+
+} // namespace xpbd

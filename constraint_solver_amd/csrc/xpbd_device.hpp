@@ -40,4 +40,19 @@ __device__ __forceinline__ Frame body_frame(const BodyArrays &b, uint32_t i)
     return Frame{frame_origin(pos, rot, com), rot};
 }
 
+// A frame stored as 7 SoA fields (origin xyz, rotation s x y z).
+__device__ __forceinline__ Frame load_frame(const double *frames, uint32_t stride, uint32_t i)
+{
+    return Frame{load3(frames, 0, stride, i), load_quat(frames, 3, stride, i)};
+}
+
+__device__ __forceinline__ void store_frame(double *frames, uint32_t stride, uint32_t i, const Frame &f)
+{
+    store3(frames, 0, stride, i, f.position);
+    frames[(size_t)3 * stride + i] = f.rotation.s;
+    frames[(size_t)4 * stride + i] = f.rotation.x;
+    frames[(size_t)5 * stride + i] = f.rotation.y;
+    frames[(size_t)6 * stride + i] = f.rotation.z;
+}
+
 } // namespace xpbd

@@ -15,116 +15,10 @@
 // math, not a contraction.  State lives in registers across substeps; shape
 // vertex tables sit in LDS; every global access is a contiguous 512-byte wave
 // access on the SoA arrays (xpbd_kernels.h).
-#include "xpbd_device.hpp"
+#include "xpbd_step.hpp"
 
 namespace xpbd {
 namespace {
-
-// ---------------------------------------------------------------------------
-// Per-body state held in registers.
-// ---------------------------------------------------------------------------
-struct BodyStatic {
-    double inv_mass;
-    Mat3 inv_inertia;
-    Vec3 ext_force, int_force, ext_torque, int_torque;
-    Vec3 com;
-};
-
-struct BodyDynamic {
-    Vec3 pos;
-    Quat rot;
-    Vec3 vel;
-    Vec3 ang;
-};
-
-// One substep of solver::step for one body.  Returns the ground-contact mask
-// (bit v set <=> shape vertex v produced a constraint, src/collision.rs:18).
-//
-// ground() only reads the post-integrate pose and the past frame, and solve()
-// consumes the constraints in push order, so no constraint list is stored:
-// constraint v is rebuilt from the frozen post-integrate frame `cur` and
-// immediately projected onto the live pose (pos, rot).  The arithmetic and its
-// order per constraint are exactly the reference's.
-__device__ __forceinline__ uint32_t substep(BodyDynamic &d, const BodyStatic &s, double h, double compliance,
-                                            const double *verts, uint32_t n_verts)
-{
-    // src/solver.rs:7-9
-    const Vec3 past_pos = d.pos;
-    const Quat past_rot = d.rot;
-    const Frame past{frame_origin(d.pos, d.rot, s.com), d.rot};
-
-    // Rigid::integrate, src/rigid.rs:82-99
-    {
-        const Vec3 force = s.ext_force + d.rot * s.int_force;
-        d.vel = d.vel + (h * force) * s.inv_mass;
-        d.pos = d.pos + h * d.vel;
-
-        const Vec3 torque = s.ext_torque + d.rot * s.int_torque;
-        d.ang = d.ang + (h * s.inv_inertia) * torque;
-        const Quat dq = ((h * 0.5) * Quat{0.0, d.ang.x, d.ang.y, d.ang.z}) * d.rot;
-        d.rot = normalized(d.rot + dq);
-    }
-
-    // Frame of the integrated body, frozen for the whole of ground() (src/collision.rs:17,24),
-    // and its inverse (src/frame.rs:30-37), shared by every penetrating vertex.
-    const Frame cur{frame_origin(d.pos, d.rot, s.com), d.rot};
-    const Frame cur_inv = inverse(cur);
-
-    // Pass 1 -- the `position.z >= 0.0` test of every vertex (src/collision.rs:17-18).  Only the
-    // z component of frame * vertex is live here, so the compiler drops the x/y arithmetic.
-    // (A NaN height fails `>=` and therefore IS a contact, as in the reference.)
-    uint32_t mask = 0;
-    for (uint32_t v = 0; v < n_verts; ++v) {
-        const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
-        const Vec3 x = cur * vertex;
-        if (!(x.z >= 0.0))
-            mask |= 1u << v;
-    }
-
-    // Pass 2 -- each lane walks ITS OWN penetrating vertices in ascending index order (the
-    // reference's push order).  Lane-compacting the contact work this way makes a wave run the
-    // expensive body max-over-lanes(contact count) times instead of once per shape vertex with
-    // most lanes masked off (resting boxes: ~4 instead of 8 trips, at twice the lane utilisation).
-    // Recomputing x for the chosen vertex repeats the pass-1 arithmetic exactly, so the bits match.
-    for (uint32_t todo = mask; todo != 0; todo &= todo - 1) {
-        const uint32_t v = __ffs(todo) - 1;
-        const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
-        const Vec3 x = cur * vertex;          // src/collision.rs:17
-
-        // src/collision.rs:22-29
-        const Vec3 target{x.x, x.y, 0.0};
-        const Vec3 correction = target - x;
-        const Vec3 local = cur_inv * x;               // src/frame.rs:41
-        const Vec3 delta = x - past * local;          // src/frame.rs:42-43
-        const Vec3 delta_tangential = delta - project_on(delta, correction);
-        const Vec3 c0 = x;
-        const Vec3 c1 = target - 1.0 * delta_tangential;
-
-        // solver::solve body, src/solver.rs:23-25 (distance == 0.0, src/collision.rs:30)
-        const Vec3 difference = c1 - c0;                       // src/constraint.rs:13-15
-        const double current_distance = length(difference);    // src/constraint.rs:21-23
-        const Vec3 direction = difference * (1.0 / current_distance); // src/constraint.rs:17-19
-        // inverse_resitance, src/constraint.rs:25-32 (reads the LIVE pose)
-        const Vec3 angular_impulse = conjugate(d.rot) * cross(c0 - (d.pos + s.com), direction);
-        const double w = s.inv_mass + dot(s.inv_inertia * angular_impulse, angular_impulse);
-        const double lagrange = (current_distance - 0.0) / (w + compliance);
-        // act -> apply_impulse, src/constraint.rs:34-37, src/rigid.rs:113-123
-        const Vec3 impulse = lagrange * direction;
-        d.pos = d.pos + impulse * s.inv_mass;
-        const Vec3 arm = c0 - (d.pos + s.com);
-        const Quat spin = quat_sv(0.0, cross(s.inv_inertia * arm, impulse));
-        d.rot = d.rot + (0.5 * spin) * d.rot;
-        d.rot = normalized(d.rot);
-    }
-
-    // Rigid::derive, src/rigid.rs:101-109
-    d.vel = (d.pos - past_pos) / h;
-    Quat dr = d.rot * conjugate(past_rot);
-    if (dr.s < 0.0)
-        dr = -dr;
-    d.ang = (2.0 * vec_of(dr)) / h;
-    return mask;
-}
 
 // ---------------------------------------------------------------------------
 // k_step: `substeps` substeps for every body in one launch.
@@ -153,23 +47,8 @@ __global__ void __launch_bounds__(kMaxStepBlock, XPBD_STEP_MIN_WAVES_PER_SIMD) k
         return;
     const uint32_t st = b.stride;
 
-    BodyStatic s;
-    s.inv_mass = b.stat[(size_t)S_INV_MASS * st + i];
-    s.inv_inertia.cx = load3(b.stat, S_INV_INERTIA + 0, st, i);
-    s.inv_inertia.cy = load3(b.stat, S_INV_INERTIA + 3, st, i);
-    s.inv_inertia.cz = load3(b.stat, S_INV_INERTIA + 6, st, i);
-    s.ext_force = load3(b.stat, S_EXT_FORCE, st, i);
-    s.int_force = load3(b.stat, S_INT_FORCE, st, i);
-    s.ext_torque = load3(b.stat, S_EXT_TORQUE, st, i);
-    s.int_torque = load3(b.stat, S_INT_TORQUE, st, i);
-    s.com = load3(b.stat, S_COM, st, i);
-
-    BodyDynamic d;
-    d.pos = load3(b.dyn, D_POS, st, i);
-    d.rot = Quat{b.dyn[(size_t)(D_ROT + 0) * st + i], b.dyn[(size_t)(D_ROT + 1) * st + i],
-                 b.dyn[(size_t)(D_ROT + 2) * st + i], b.dyn[(size_t)(D_ROT + 3) * st + i]};
-    d.vel = load3(b.dyn, D_VEL, st, i);
-    d.ang = load3(b.dyn, D_ANG, st, i);
+    const BodyStatic s = load_static(b, i);
+    BodyDynamic d = load_dynamic(b.dyn, st, i);
 
     const uint32_t sid = b.shape_id[i];
     const uint32_t v0 = lds_off[sid];
@@ -185,13 +64,7 @@ __global__ void __launch_bounds__(kMaxStepBlock, XPBD_STEP_MIN_WAVES_PER_SIMD) k
             trace_masks[(size_t)(trace_row0 + k) * st + i] = mask;
     }
 
-    store3(b.dyn, D_POS, st, i, d.pos);
-    b.dyn[(size_t)(D_ROT + 0) * st + i] = d.rot.s;
-    b.dyn[(size_t)(D_ROT + 1) * st + i] = d.rot.x;
-    b.dyn[(size_t)(D_ROT + 2) * st + i] = d.rot.y;
-    b.dyn[(size_t)(D_ROT + 3) * st + i] = d.rot.z;
-    store3(b.dyn, D_VEL, st, i, d.vel);
-    store3(b.dyn, D_ANG, st, i, d.ang);
+    store_dynamic(b.dyn, st, i, d);
     last_mask[i] = mask;
 }
 

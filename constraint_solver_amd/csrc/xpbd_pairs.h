@@ -29,6 +29,7 @@ struct PolytopeTables {
     const uint32_t *face_start;  // [total_faces + 1] offsets into face_verts
     const uint32_t *face_verts;  // shape-local vertex indices of every face, back to back
     const uint32_t *edges;       // [total_edges][2] shape-local vertex indices
+    const double *radii;         // [n_shapes] max |vertex - centroid|
     uint32_t n_shapes;
 };
 
@@ -47,8 +48,9 @@ struct Manifold {
     double p_inc[kMaxManifoldPoints][3];
 };
 
-// One wave per pair: pairs[2*p], pairs[2*p+1] are body indices (A, B).
-hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const uint32_t *pairs, uint32_t n_pairs,
-                            Manifold *out, hipStream_t stream);
+// One wave per pair: pairs[2*p], pairs[2*p+1] are body indices (A, B).  frames: [7][stride] object->world
+// frames of all bodies (origin xyz, rotation s x y z).  stats (optional): [0] += touching pairs, [1] += points.
+hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream);
 
 } // namespace xpbd

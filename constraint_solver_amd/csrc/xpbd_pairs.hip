@@ -96,8 +96,9 @@ __device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint3
 
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
-__global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t, const uint32_t *__restrict__ pairs,
-                                                  uint32_t n_pairs, Manifold *__restrict__ out)
+__global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+                                                  const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                  Manifold *__restrict__ out, unsigned long long *__restrict__ stats)
 {
     __shared__ PairLds s;
     const uint32_t p = blockIdx.x;
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
 
     // ---- wave-uniform inputs -------------------------------------------------------------------
     const uint32_t ia = pairs[2 * p], ib = pairs[2 * p + 1];
-    const Frame fa = body_frame(b, ia), fb = body_frame(b, ib);
+    const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
     const Frame fa_inv = inverse(fa), fb_inv = inverse(fb);
     const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
     const ShapeDesc da = t.desc[sa], db = t.desc[sb];
@@ -246,6 +247,10 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
             m->separation = ebest;
             m->p_ref[0][0] = pa.x, m->p_ref[0][1] = pa.y, m->p_ref[0][2] = pa.z;
             m->p_inc[0][0] = pb.x, m->p_inc[0][1] = pb.y, m->p_inc[0][2] = pb.z;
+            if (stats) {
+                atomicAdd(&stats[0], 1ull);
+                atomicAdd(&stats[1], 1ull);
+            }
         }
         return;
     }
@@ -320,15 +325,19 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     m->index_a = r ? iface : face_a;
     m->index_b = r ? face_b : iface;
     m->separation = face_best;
+    if (stats && n_out) {
+        atomicAdd(&stats[0], 1ull);
+        atomicAdd(&stats[1], (unsigned long long)n_out);
+    }
 }
 
 } // namespace
 
-hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const uint32_t *pairs, uint32_t n_pairs,
-                            Manifold *out, hipStream_t stream)
+hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream)
 {
     if (n_pairs)
-        hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, pairs, n_pairs, out);
+        hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, stats);
     return hipGetLastError();
 }
 

@@ -9,12 +9,14 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
 
 #include "xpbd_kernels.h"
 #include "xpbd_math.hpp"
+#include "xpbd_contacts.h"
 #include "xpbd_pairs.h"
 
 namespace {
@@ -98,12 +100,47 @@ struct xpbd_world {
 
     // extension: polytope topology for the body-body narrowphase
     DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
+    DeviceBuffer shape_radii;
     bool has_topology = false;
     xpbd::PolytopeTables tables() const
     {
         return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
                                     shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
-                                    face_verts.as<uint32_t>(), edges.as<uint32_t>(), n_shapes};
+                                    face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(), n_shapes};
+    }
+
+    // extension: contact pipeline (XPBD_MODE_CONTACTS)
+    double contact_pad = 0.02;
+    DeviceBuffer dyn_alt, cb_centers, cb_radius, cb_cell, cb_key, cb_maxr, cb_bucket_start, cb_bucket_cursor, cb_items,
+        cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_frame_p1, cb_frame_past,
+        cb_past_pos, cb_manifolds, cb_stats, cb_scan;
+    uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
+    bool have_neighbours = false;
+    xpbd::ContactBuffers contact_buffers() const
+    {
+        xpbd::ContactBuffers c{};
+        c.centers = cb_centers.as<double>();
+        c.radius = cb_radius.as<double>();
+        c.cell = cb_cell.as<int32_t>();
+        c.key = cb_key.as<uint32_t>();
+        c.max_radius_bits = cb_maxr.as<unsigned long long>();
+        c.bucket_start = cb_bucket_start.as<uint32_t>();
+        c.bucket_cursor = cb_bucket_cursor.as<uint32_t>();
+        c.items = cb_items.as<uint32_t>();
+        c.table_size = table_size;
+        c.nbr_off = cb_nbr_off.as<uint32_t>();
+        c.pair_first = cb_pair_first.as<uint32_t>();
+        c.upper_start = cb_upper_start.as<uint32_t>();
+        c.nbr = cb_nbr.as<uint32_t>();
+        c.nbr_pair = cb_nbr_pair.as<uint32_t>();
+        c.pairs = cb_pairs.as<uint32_t>();
+        c.frame_p1 = cb_frame_p1.as<double>();
+        c.frame_past = cb_frame_past.as<double>();
+        c.past_pos = cb_past_pos.as<double>();
+        c.manifolds = cb_manifolds.as<xpbd::Manifold>();
+        c.stats = cb_stats.as<unsigned long long>();
+        c.scan_scratch = cb_scan.as<uint32_t>();
+        return c;
     }
 
     xpbd::BodyArrays arrays() const
@@ -123,6 +160,78 @@ constexpr uint32_t kDefaultBlock = 64;
 int bind_device(const xpbd_world *w)
 {
     XPBD_HIP_TRY(hipSetDevice(w->device));
+    return XPBD_OK;
+}
+
+uint32_t next_pow2(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v)
+        p <<= 1;
+    return p;
+}
+
+// Sphere broadphase of the contact pipeline: neighbour lists + pair list for the coming frame.
+int build_neighbours(xpbd_world *w, double dt)
+{
+    const uint32_t n = w->n, st = w->stride;
+    w->table_size = next_pow2(n < 512 ? 1024 : 2 * n);
+    XPBD_HIP_TRY(w->cb_centers.reserve((size_t)3 * st * 8));
+    XPBD_HIP_TRY(w->cb_radius.reserve((size_t)st * 8));
+    XPBD_HIP_TRY(w->cb_cell.reserve((size_t)3 * st * 4));
+    XPBD_HIP_TRY(w->cb_key.reserve((size_t)st * 4));
+    XPBD_HIP_TRY(w->cb_maxr.reserve(8));
+    XPBD_HIP_TRY(w->cb_bucket_start.reserve((size_t)(w->table_size + 1) * 4));
+    XPBD_HIP_TRY(w->cb_bucket_cursor.reserve((size_t)w->table_size * 4));
+    XPBD_HIP_TRY(w->cb_items.reserve((size_t)st * 4));
+    XPBD_HIP_TRY(w->cb_nbr_off.reserve((size_t)(st + 1) * 4));
+    XPBD_HIP_TRY(w->cb_pair_first.reserve((size_t)(st + 1) * 4));
+    XPBD_HIP_TRY(w->cb_upper_start.reserve((size_t)st * 4));
+    XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * st * 8));
+    XPBD_HIP_TRY(w->cb_frame_past.reserve((size_t)7 * st * 8));
+    XPBD_HIP_TRY(w->cb_past_pos.reserve((size_t)3 * st * 8));
+    XPBD_HIP_TRY(w->cb_scan.reserve(((size_t)(w->table_size > st ? w->table_size : st) / 1024 + 8) * 4));
+    if (!w->cb_stats.ptr) {
+        XPBD_HIP_TRY(w->cb_stats.reserve(16));
+        XPBD_HIP_TRY(hipMemsetAsync(w->cb_stats.ptr, 0, 16, w->stream));
+    }
+    const xpbd::BodyArrays b = w->arrays();
+    xpbd::ContactBuffers c = w->contact_buffers();
+    XPBD_HIP_TRY(xpbd::launch_bounds_and_cells(b, w->tables(), w->shape_radii.as<double>(), dt, w->contact_pad, c,
+                                               w->stream));
+    XPBD_HIP_TRY(xpbd::launch_build_buckets(b, c, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_neighbour_count(b, c, w->stream));
+    uint32_t totals[2] = {0, 0};
+    XPBD_HIP_TRY(hipMemcpyAsync(&totals[0], c.nbr_off + n, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(&totals[1], c.pair_first + n, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    w->n_entries = totals[0];
+    w->n_pairs = totals[1];
+    XPBD_HIP_TRY(w->cb_nbr.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
+    XPBD_HIP_TRY(w->cb_nbr_pair.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
+    XPBD_HIP_TRY(w->cb_pairs.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 8));
+    XPBD_HIP_TRY(w->cb_manifolds.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * sizeof(xpbd::Manifold)));
+    c = w->contact_buffers();
+    XPBD_HIP_TRY(xpbd::launch_neighbour_fill(b, c, w->stream));
+    w->have_neighbours = true;
+    return XPBD_OK;
+}
+
+// One xpbd_world_step in XPBD_MODE_CONTACTS (semantics: oracle/xpbd_pairs_oracle.h).
+int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_t *trace)
+{
+    if (!w->has_topology)
+        return fail(XPBD_E_INVALID, "XPBD_MODE_CONTACTS needs xpbd_world_set_polytopes");
+    if (int rc = build_neighbours(w, dt))
+        return rc;
+    for (uint32_t k = 0; k < substeps; ++k) {
+        const xpbd::BodyArrays b = w->arrays();
+        const xpbd::ContactBuffers c = w->contact_buffers();
+        XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, k, w->stream));
+        XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
+        XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
+        std::swap(w->dyn, w->dyn_alt);
+    }
     return XPBD_OK;
 }
 
@@ -166,7 +275,7 @@ int xpbd_world_create(xpbd_world **out, const xpbd_config *cfg)
                         sizeof(xpbd_config));
         c = *cfg;
     }
-    if (c.mode != XPBD_MODE_FUSED && c.mode != XPBD_MODE_PER_SUBSTEP)
+    if (c.mode != XPBD_MODE_FUSED && c.mode != XPBD_MODE_PER_SUBSTEP && c.mode != XPBD_MODE_CONTACTS)
         return fail(XPBD_E_INVALID, "xpbd_world_create: unknown mode %u", c.mode);
     if (c.flags & ~XPBD_FLAG_TRACE_CONTACTS)
         return fail(XPBD_E_INVALID, "xpbd_world_create: unknown flags 0x%x", c.flags);
@@ -213,7 +322,11 @@ void xpbd_world_destroy(xpbd_world *w)
     for (DeviceBuffer *b : {&w->dyn, &w->stat, &w->shape_id, &w->aos_staging, &w->last_mask, &w->trace,
                             &w->block_counts, &w->contacts, &w->shape_verts, &w->shape_offsets, &w->planes,
                             &w->centroids, &w->shape_desc, &w->face_start, &w->face_verts, &w->edges, &w->pair_buf,
-                            &w->manifold_buf})
+                            &w->manifold_buf, &w->shape_radii, &w->dyn_alt, &w->cb_centers, &w->cb_radius, &w->cb_cell,
+                            &w->cb_key, &w->cb_maxr, &w->cb_bucket_start, &w->cb_bucket_cursor, &w->cb_items,
+                            &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
+                            &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
+                            &w->cb_stats, &w->cb_scan})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
@@ -257,7 +370,7 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
 {
     if (!w || !shapes || n_shapes == 0)
         return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: NULL argument or no shapes");
-    std::vector<double> verts, planes, centroids;
+    std::vector<double> verts, planes, centroids, radii;
     std::vector<uint32_t> vert_offsets{0}, face_start{0}, face_verts, edges;
     std::vector<xpbd::ShapeDesc> desc;
     for (uint32_t s = 0; s < n_shapes; ++s) {
@@ -310,6 +423,13 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
             planes.insert(planes.end(), {n.x, n.y, n.z, disp});
         }
         centroids.insert(centroids.end(), {centroid.x, centroid.y, centroid.z});
+        double radius = 0.0; // bounding sphere about the centroid
+        for (uint32_t k = 0; k < p.n_vertices; ++k) {
+            const double dist = xpbd::length(vertex(k) - centroid);
+            if (dist > radius)
+                radius = dist;
+        }
+        radii.push_back(radius);
         desc.push_back(d);
     }
     static const double zero3[3] = {0, 0, 0};
@@ -327,6 +447,7 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
     XPBD_HIP_TRY(upload(w->face_start, face_start.data(), face_start.size() * 4));
     XPBD_HIP_TRY(upload(w->face_verts, face_verts.data(), face_verts.size() * 4));
     XPBD_HIP_TRY(upload(w->edges, edges.data(), edges.size() * 4));
+    XPBD_HIP_TRY(upload(w->shape_radii, radii.data(), radii.size() * 8));
     w->has_topology = true;
     return XPBD_OK;
 }
@@ -350,8 +471,10 @@ int xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pair
     XPBD_HIP_TRY(w->manifold_buf.reserve((size_t)n_pairs * sizeof(xpbd::Manifold)));
     XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
     XPBD_HIP_TRY(hipMemsetAsync(w->manifold_buf.ptr, 0, (size_t)n_pairs * sizeof(xpbd::Manifold), w->stream));
-    XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->pair_buf.as<uint32_t>(), n_pairs,
-                                        w->manifold_buf.as<xpbd::Manifold>(), w->stream));
+    XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * w->stride * 8));
+    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(), w->pair_buf.as<uint32_t>(),
+                                        n_pairs, w->manifold_buf.as<xpbd::Manifold>(), nullptr, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::Manifold),
                                 hipMemcpyDeviceToHost, w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
@@ -374,6 +497,8 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     const uint32_t stride = round_up(n ? n : 1, 256);
     XPBD_HIP_TRY(w->dyn.reserve((size_t)xpbd::kDynFields * stride * 8));
+    XPBD_HIP_TRY(w->dyn_alt.reserve((size_t)xpbd::kDynFields * stride * 8));
+    w->have_neighbours = false;
     XPBD_HIP_TRY(w->stat.reserve((size_t)xpbd::kStatFields * stride * 8));
     XPBD_HIP_TRY(w->shape_id.reserve((size_t)stride * 4));
     XPBD_HIP_TRY(w->last_mask.reserve((size_t)stride * 4));
@@ -436,7 +561,10 @@ int xpbd_world_step(xpbd_world *w, double dt, uint32_t substeps)
         trace = w->trace.as<uint32_t>();
         w->trace_rows = substeps;
     }
-    if (w->mode == XPBD_MODE_FUSED) {
+    if (w->mode == XPBD_MODE_CONTACTS) {
+        if (int rc = step_contacts(w, dt, h, substeps, trace))
+            return rc;
+    } else if (w->mode == XPBD_MODE_FUSED) {
         XPBD_HIP_TRY(xpbd::launch_step(w->arrays(), w->shapes(), h, substeps, w->last_mask.as<uint32_t>(), trace, 0,
                                        w->block_size, w->stream));
     } else {
@@ -525,7 +653,7 @@ void *xpbd_world_get_stream(const xpbd_world *w) { return w ? static_cast<void *
 
 int xpbd_world_set_mode(xpbd_world *w, uint32_t mode)
 {
-    if (!w || (mode != XPBD_MODE_FUSED && mode != XPBD_MODE_PER_SUBSTEP))
+    if (!w || (mode != XPBD_MODE_FUSED && mode != XPBD_MODE_PER_SUBSTEP && mode != XPBD_MODE_CONTACTS))
         return fail(XPBD_E_INVALID, "xpbd_world_set_mode: bad argument");
     w->mode = mode;
     return XPBD_OK;
@@ -556,6 +684,64 @@ int xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts, d
     if (int rc = xpbd_world_step(cache.w, dt, substeps))
         return rc;
     return xpbd_world_download_bodies(cache.w, rigid, 1);
+}
+
+int xpbd_world_set_contact_pad(xpbd_world *w, double pad)
+{
+    if (!w || !(pad >= 0.0) || pad > 1.0e6)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_contact_pad: bad argument");
+    w->contact_pad = pad;
+    return XPBD_OK;
+}
+
+int xpbd_world_contact_stats(xpbd_world *w, uint64_t out[3])
+{
+    if (!w || !out)
+        return fail(XPBD_E_INVALID, "xpbd_world_contact_stats: NULL argument");
+    out[0] = w->n_pairs;
+    out[1] = out[2] = 0;
+    if (!w->cb_stats.ptr)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    unsigned long long host[2] = {0, 0};
+    XPBD_HIP_TRY(hipMemcpyAsync(host, w->cb_stats.ptr, 16, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipMemsetAsync(w->cb_stats.ptr, 0, 16, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    out[1] = host[0];
+    out[2] = host[1];
+    return XPBD_OK;
+}
+
+int xpbd_world_build_neighbours(xpbd_world *w, double dt, uint32_t *n_entries_out)
+{
+    if (!w || !n_entries_out)
+        return fail(XPBD_E_INVALID, "xpbd_world_build_neighbours: NULL argument");
+    if (!w->has_topology)
+        return fail(XPBD_E_INVALID, "xpbd_world_build_neighbours: call xpbd_world_set_polytopes first");
+    if (int rc = bind_device(w))
+        return rc;
+    if (int rc = build_neighbours(w, dt))
+        return rc;
+    *n_entries_out = w->n_entries;
+    return XPBD_OK;
+}
+
+int xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *neighbours, uint32_t cap)
+{
+    if (!w || !offsets || (!neighbours && cap))
+        return fail(XPBD_E_INVALID, "xpbd_world_download_neighbours: NULL argument");
+    if (!w->have_neighbours)
+        return fail(XPBD_E_INVALID, "xpbd_world_download_neighbours: no neighbour lists built yet");
+    if (cap < w->n_entries)
+        return fail(XPBD_E_CAPACITY, "xpbd_world_download_neighbours: %u entries, capacity %u", w->n_entries, cap);
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipMemcpyAsync(offsets, w->cb_nbr_off.ptr, (size_t)(w->n + 1) * 4, hipMemcpyDeviceToHost, w->stream));
+    if (w->n_entries)
+        XPBD_HIP_TRY(hipMemcpyAsync(neighbours, w->cb_nbr.ptr, (size_t)w->n_entries * 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
 }
 
 int xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b, double *quotient, double *root,

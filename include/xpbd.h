@@ -79,6 +79,7 @@ typedef struct xpbd_contact {
 /* How xpbd_world_step schedules the substep loop. */
 #define XPBD_MODE_FUSED        0u /* one launch runs all substeps in registers (bodies are independent) */
 #define XPBD_MODE_PER_SUBSTEP  1u /* one launch per substep: state round-trips HBM each substep */
+#define XPBD_MODE_CONTACTS     2u /* EXTENSION: ground + body-body contacts (needs xpbd_world_set_polytopes) */
 
 #define XPBD_FLAG_TRACE_CONTACTS 1u /* keep the contact mask of every substep of the last step() call */
 
@@ -188,6 +189,19 @@ int  xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32
  * world's current poses: one wave per pair.  out has n_pairs entries. */
 int  xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs,
                             xpbd_manifold *out);
+
+/* XPBD_MODE_CONTACTS: per xpbd_world_step a sphere broadphase builds sorted neighbour lists
+ * (sphere = centroid, r_shape + |v| dt + pad); per substep: integrate -> SAT of every neighbour
+ * pair -> ground contacts (reference path) -> pair contacts, Jacobi-averaged with a fixed
+ * summation order -> derive.  Exact semantics: oracle/xpbd_pairs_oracle.h.  With no overlapping
+ * spheres the result equals XPBD_MODE_PER_SUBSTEP bit for bit. */
+int  xpbd_world_set_contact_pad(xpbd_world *w, double pad);            /* default 0.02 (metres) */
+/* out = {neighbour pairs of the last step, touching pairs, manifold points}; the last two are
+ * summed over substeps since the previous call and then reset. */
+int  xpbd_world_contact_stats(xpbd_world *w, uint64_t out[3]);
+/* Broadphase alone (as the next step(dt, .) would run it) and its CSR neighbour lists. */
+int  xpbd_world_build_neighbours(xpbd_world *w, double dt, uint32_t *n_entries_out);
+int  xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *neighbours, uint32_t cap);
 
 /* Diagnostics: quotient[i] = a[i] / b[i], root[i] = sqrt(a[i]) computed on the
  * device with the stepper's own code generation.  Bit-exact contact lists need

@@ -222,3 +222,205 @@ void op_sat(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, 
         face_contact(fb, pb, (uint32_t)face_b, fa, pa, &out->index_a, out);
     }
 }
+
+/* ======================================================================
+ * N-body step with body-body contacts (semantics: xpbd_pairs_oracle.h)
+ * ====================================================================== */
+#include <stdlib.h>
+
+static double shape_radius(const o_polytope *p)
+{
+    double r = 0.0;
+    for (uint32_t k = 0; k < p->n_vertices; k++) {
+        double d = o_magnitude(o_sub(p->vertices[k], p->centroid));
+        if (d > r)
+            r = d;
+    }
+    return r;
+}
+
+void op_broadphase(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                   double dt, double pad, uint32_t **offsets_out, uint32_t **neighbours_out)
+{
+    o_vec3 *c = (o_vec3 *)malloc(sizeof(o_vec3) * (n ? n : 1));
+    double *r = (double *)malloc(sizeof(double) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; i++) {
+        const o_polytope *p = &shapes[shape_id ? shape_id[i] : 0];
+        c[i] = o_frame_mulv(o_rigid_frame(&bodies[i]), p->centroid);
+        r[i] = shape_radius(p) + o_magnitude(bodies[i].velocity) * dt + pad;
+    }
+    uint32_t *off = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    size_t cap = 16, cnt = 0;
+    uint32_t *nb = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; i++) {
+        off[i] = (uint32_t)cnt;
+        for (uint32_t j = 0; j < n; j++) {
+            if (j == i)
+                continue;
+            o_vec3 d = o_sub(c[i], c[j]);
+            double reach = r[i] + r[j];
+            if (o_dot(d, d) < reach * reach) {
+                if (cnt == cap) {
+                    cap *= 2;
+                    nb = (uint32_t *)realloc(nb, cap * sizeof(uint32_t));
+                }
+                nb[cnt++] = j;
+            }
+        }
+    }
+    off[n] = (uint32_t)cnt;
+    free(c);
+    free(r);
+    *offsets_out = off;
+    *neighbours_out = nb;
+}
+
+/* Generalized inverse mass of `body` for an impulse along dir at `point` (src/constraint.rs:25-32). */
+static double generalized_inverse_mass(const o_rigid *body, o_vec3 point, o_vec3 dir)
+{
+    o_vec3 angular_impulse = o_qrot(o_qconj(body->rotation),
+                                    o_cross(o_sub(point, o_add(body->position, body->center_of_mass)), dir));
+    return body->inverse_mass + o_dot(o_mat3_mulv(body->inverse_inertia, angular_impulse), angular_impulse);
+}
+
+typedef struct {
+    o_vec3 dpos;
+    o_quat drot;
+    uint32_t count;
+} pair_accum;
+
+/* One manifold point seen from body `self_is_inc ? inc : ref`. */
+static void accumulate_point(int self_is_inc, const o_rigid *inc, const o_rigid *ref, o_frame inc_p1, o_frame inc_past,
+                             o_frame ref_p1, o_frame ref_past, o_vec3 p_inc, o_vec3 p_ref, double compliance,
+                             pair_accum *acc)
+{
+    o_vec3 correction = o_sub(p_ref, p_inc);
+    o_vec3 delta_rel = o_sub(o_frame_delta(inc_p1, inc_past, p_inc), o_frame_delta(ref_p1, ref_past, p_ref));
+    o_vec3 delta_tangential = o_sub(delta_rel, o_project_on(delta_rel, correction));
+    o_vec3 c0 = p_inc;
+    o_vec3 c1 = o_sub(p_ref, o_lscale(1.0, delta_tangential));
+    o_vec3 difference = o_sub(c1, c0);
+    double distance = o_magnitude(difference);
+    o_vec3 dir = o_scale(difference, 1.0 / distance);
+    double w = generalized_inverse_mass(inc, c0, dir) + generalized_inverse_mass(ref, p_ref, dir);
+    double lambda = (distance - 0.0) / (w + compliance);
+
+    const o_rigid *self = self_is_inc ? inc : ref;
+    o_vec3 point = self_is_inc ? c0 : p_ref;
+    o_vec3 impulse = self_is_inc ? o_lscale(lambda, dir) : o_lscale(-lambda, dir);
+    acc->dpos = o_add(acc->dpos, o_scale(impulse, self->inverse_mass));
+    o_vec3 arm = o_sub(point, o_add(self->position, self->center_of_mass));
+    o_quat spin = { 0.0, o_cross(o_mat3_mulv(self->inverse_inertia, arm), impulse) };
+    acc->drot = o_qadd(acc->drot, o_qmul(o_qlscale(0.5, spin), self->rotation));
+    acc->count++;
+}
+
+void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                      double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats)
+{
+    uint32_t *off, *nb;
+    op_broadphase(bodies, shape_id, n, shapes, dt, pad, &off, &nb);
+    /* pair index of (i, j), i < j: pair_first[i] + rank of j among i's neighbours > i */
+    uint32_t *pair_first = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    uint32_t n_pairs = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        pair_first[i] = n_pairs;
+        for (uint32_t k = off[i]; k < off[i + 1]; k++)
+            n_pairs += nb[k] > i;
+    }
+    pair_first[n] = n_pairs;
+    op_manifold *manifolds = (op_manifold *)malloc(sizeof(op_manifold) * (n_pairs ? n_pairs : 1));
+    o_frame *past = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
+    o_frame *p1 = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
+    o_vec3 *past_pos = (o_vec3 *)malloc(sizeof(o_vec3) * (n ? n : 1));
+    o_rigid *next = (o_rigid *)malloc(sizeof(o_rigid) * (n ? n : 1));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_pairs = n_pairs;
+    }
+    const double h = dt / (double)substeps;
+    const double compliance = 1e-6 / (h * h);
+
+    for (uint32_t step = 0; step < substeps; step++) {
+        /* 1. integrate */
+        for (uint32_t i = 0; i < n; i++) {
+            past[i] = o_rigid_frame(&bodies[i]);
+            past_pos[i] = bodies[i].position;
+            o_rigid_integrate(&bodies[i], h);
+            p1[i] = o_rigid_frame(&bodies[i]);
+        }
+        /* 2. narrowphase on the post-integrate frames */
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t q = pair_first[i];
+            for (uint32_t k = off[i]; k < off[i + 1]; k++) {
+                uint32_t j = nb[k];
+                if (j <= i)
+                    continue;
+                op_sat(p1[i], p1[j], &shapes[shape_id ? shape_id[i] : 0], &shapes[shape_id ? shape_id[j] : 0],
+                       &manifolds[q]);
+                if (manifolds[q].separated)
+                    manifolds[q].n_points = 0;
+                if (stats && manifolds[q].n_points) {
+                    stats->n_touching++;
+                    stats->n_points += manifolds[q].n_points;
+                }
+                q++;
+            }
+        }
+        /* 3. ground contacts, sequential per body (reference path) */
+        for (uint32_t i = 0; i < n; i++) {
+            const o_polytope *p = &shapes[shape_id ? shape_id[i] : 0];
+            o_constraint cs[O_MAX_VERTS];
+            uint32_t cv[O_MAX_VERTS];
+            uint32_t nc = o_ground(&bodies[i], past[i], p->vertices, p->n_vertices, cs, cv);
+            o_solve(&bodies[i], cs, nc, h);
+            if (ground_masks) {
+                uint32_t mask = 0;
+                for (uint32_t c = 0; c < nc; c++)
+                    mask |= 1u << cv[c];
+                ground_masks[(size_t)step * n + i] = mask;
+            }
+        }
+        /* 4. pair contacts, Jacobi with averaging; reads bodies[], writes next[] */
+        for (uint32_t b = 0; b < n; b++) {
+            pair_accum acc;
+            memset(&acc, 0, sizeof acc);
+            for (uint32_t k = off[b]; k < off[b + 1]; k++) {
+                uint32_t j = nb[k];
+                uint32_t a_body = b < j ? b : j, b_body = b < j ? j : b;
+                /* pair index: rank of b_body among a_body's upper neighbours */
+                uint32_t q = pair_first[a_body];
+                for (uint32_t t = off[a_body]; nb[t] != b_body; t++)
+                    q += nb[t] > a_body;
+                const op_manifold *m = &manifolds[q];
+                if (m->n_points == 0)
+                    continue;
+                int ref_is_a = m->feature != OP_FEATURE_FACE_B;
+                uint32_t ref = ref_is_a ? a_body : b_body, inc = ref_is_a ? b_body : a_body;
+                for (uint32_t pt = 0; pt < m->n_points; pt++)
+                    accumulate_point(inc == b, &bodies[inc], &bodies[ref], p1[inc], past[inc], p1[ref], past[ref],
+                                     m->p_inc[pt], m->p_ref[pt], compliance, &acc);
+            }
+            next[b] = bodies[b];
+            if (acc.count) {
+                double cnt = (double)acc.count;
+                next[b].position = o_add(bodies[b].position, o_divs(acc.dpos, cnt));
+                o_quat avg = { acc.drot.s / cnt, o_divs(acc.drot.v, cnt) };
+                next[b].rotation = o_qnormalize(o_qadd(bodies[b].rotation, avg));
+            }
+        }
+        /* 5. derive */
+        for (uint32_t i = 0; i < n; i++) {
+            bodies[i] = next[i];
+            o_rigid_derive(&bodies[i], past_pos[i], past[i].rotation, h);
+        }
+    }
+    free(off);
+    free(nb);
+    free(pair_first);
+    free(manifolds);
+    free(past);
+    free(p1);
+    free(past_pos);
+    free(next);
+}

@@ -53,6 +53,41 @@ double op_edge_query(o_frame fa, o_frame fb, const o_polytope *pa, const o_polyt
                      uint64_t *edge_b);
 void op_sat(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, op_manifold *out);
 
+/* ---------------------------------------------------------------------------
+ * N-body step with body-body contacts (extension; parity unpinned).
+ *
+ * Once per call (broadphase):  bounding sphere of body b = (frame_b * centroid,
+ *   r_shape + |v_b| * dt + pad);  j is a neighbour of b iff the spheres overlap
+ *   (strict '<' on squared distances).  Neighbour lists are sorted by index.
+ * Per substep (h = dt / substeps), for all bodies in lock step:
+ *   1. past = pose; Rigid::integrate(h); P1 = Rigid::frame()            (src/solver.rs:7-10)
+ *   2. manifold(i,j) = op_sat(P1_i, P1_j) for every neighbour pair i < j
+ *   3. ground contacts from P1, solved sequentially per body              (src/solver.rs:12-13, unchanged)
+ *   4. pair contacts, Jacobi: every contact point computes its XPBD correction from the
+ *      poses after step 3; a body adds the corrections of all its points in (neighbour
+ *      index, point index) order and applies their AVERAGE.  Each point is a two-body
+ *      version of the reference Constraint (src/constraint.rs:6-37): c0 = the incident
+ *      body's point, c1 = the reference body's surface point minus the relative
+ *      tangential motion of the two material points during the substep (the positional
+ *      friction of collision::ground, src/collision.rs:24-29), lambda = |c1 - c0| /
+ *      (w_inc + w_ref + compliance), +lambda*dir on the incident body at c0 and
+ *      -lambda*dir on the reference body at its surface point.
+ *   5. Rigid::derive(past, h)                                              (src/solver.rs:15)
+ * With no overlapping spheres this is exactly o_step_bodies.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t n_pairs;          /* neighbour pairs i < j of the call */
+    uint64_t n_touching;       /* sum over substeps of pairs with n_points > 0 */
+    uint64_t n_points;         /* sum over substeps of manifold points */
+} op_contact_stats;
+
+/* CSR neighbour lists (sorted ascending), malloc'ed; caller frees both. */
+void op_broadphase(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                   double dt, double pad, uint32_t **offsets_out, uint32_t **neighbours_out);
+
+void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                      double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,60 @@ def sat(fa, fb, pa, pb):
     m = Manifold()
     L.op_sat(frame(*fa), frame(*fb), C.byref(pa), C.byref(pb), C.byref(m))
     return m
+
+
+class ContactStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_touching", C.c_uint64), ("n_points", C.c_uint64)]
+
+
+def polytopes_array(names_scales):
+    """C array of oracle Polytope structs, e.g. [("cube", 1.0), ("tetrahedron", 0.5)]."""
+    arr = (Polytope * len(names_scales))()
+    for k, (name, scale) in enumerate(names_scales):
+        arr[k] = polytope(name, scale)
+    return arr
+
+
+def _contacts_api():
+    L = load()
+    if not hasattr(L, "_contacts_ready"):
+        P = C.POINTER
+        L.op_contacts_step.restype = None
+        L.op_contacts_step.argtypes = [C.c_void_p, P(C.c_uint32), C.c_uint32, P(Polytope), C.c_double, C.c_uint32,
+                                       C.c_double, P(C.c_uint32), P(ContactStats)]
+        L.op_broadphase.restype = None
+        L.op_broadphase.argtypes = [C.c_void_p, P(C.c_uint32), C.c_uint32, P(Polytope), C.c_double, C.c_double,
+                                    P(P(C.c_uint32)), P(P(C.c_uint32))]
+        L._contacts_ready = True
+    return L
+
+
+def contacts_step(bodies, shape_id, polys, dt, substeps, pad, want_masks=False):
+    """op_contacts_step: returns (new bodies, ground masks or None, stats)."""
+    L = _contacts_api()
+    b = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
+    n = b.shape[0]
+    sid = np.ascontiguousarray(shape_id if shape_id is not None else np.zeros(n), dtype=np.uint32)
+    masks = np.zeros((substeps, n), dtype=np.uint32) if want_masks else None
+    st = ContactStats()
+    u32p = C.POINTER(C.c_uint32)
+    L.op_contacts_step(b.ctypes.data, sid.ctypes.data_as(u32p), n, polys, dt, substeps, pad,
+                       masks.ctypes.data_as(u32p) if want_masks else None, C.byref(st))
+    return b, masks, st
+
+
+def broadphase(bodies, shape_id, polys, dt, pad):
+    """op_broadphase: (offsets[n+1], neighbours) as numpy arrays."""
+    L = _contacts_api()
+    b = np.ascontiguousarray(bodies, dtype=np.float64).reshape(-1, 38)
+    n = b.shape[0]
+    sid = np.ascontiguousarray(shape_id if shape_id is not None else np.zeros(n), dtype=np.uint32)
+    off, nb = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+    L.op_broadphase(b.ctypes.data, sid.ctypes.data_as(C.POINTER(C.c_uint32)), n, polys, dt, pad, C.byref(off), C.byref(nb))
+    offsets = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+    neigh = np.ctypeslib.as_array(nb, shape=(max(int(offsets[-1]), 1),)).copy()[: offsets[-1]]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(off)
+    libc.free(nb)
+    return offsets, neigh

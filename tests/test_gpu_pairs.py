@@ -100,3 +100,100 @@ def test_narrowphase_argument_errors():
         w.step(1 / 60, 20)
         want, _ = ob.step_bodies(bodies, sid, verts, off, 1 / 60, 20)
         assert bits_equal(w.download(), want)
+
+
+# ------------------------------------------------------------------------------------------------
+# Broadphase and the full contact pipeline (XPBD_MODE_CONTACTS) against op_contacts_step
+# ------------------------------------------------------------------------------------------------
+DT = 1.0 / 60.0
+POLY_NAMES = {capi.SCENE_BOXES: [("cube", 1.0)], capi.SCENE_BOXES_DROP: [("cube", 1.0)],
+              capi.SCENE_MIXED: [("cube", 1.0), ("tetrahedron", 0.5), ("icosahedron", 0.5)],
+              capi.SCENE_MIXED_DROP: [("cube", 1.0), ("tetrahedron", 0.5), ("icosahedron", 0.5)]}
+
+
+def pile(kind, n, seed, width, height):
+    """n bodies dropped over a width x width patch: they land, collide and pile up."""
+    rng = np.random.default_rng(seed)
+    bodies, sid = capi.scene_generate(kind, seed, n)
+    bodies[:, 31:33] = rng.uniform(0, width, (n, 2))
+    bodies[:, 33] = rng.uniform(0.5, height, n)
+    bodies[:, 22:25] *= 0.3
+    return bodies, sid
+
+
+@pytest.mark.parametrize("kind,n,spread", [(capi.SCENE_BOXES, 3000, 12.0), (capi.SCENE_MIXED, 2000, 6.0),
+                                           (capi.SCENE_BOXES, 70, 1.0)])
+def test_broadphase_matches_brute_force(kind, n, spread):
+    bodies, sid = cluster(kind, n, 5, spread)
+    bodies[::7, 22:25] *= 30.0                                     # some fast bodies: radius grows with |v| dt
+    with capi.World() as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.upload(bodies, sid)
+        w.set_contact_pad(0.05)
+        off, nb = w.neighbours(DT)
+    want_off, want_nb = ob.broadphase(bodies, sid, ob.polytopes_array(POLY_NAMES[kind]), DT, 0.05)
+    assert np.array_equal(off, want_off) and np.array_equal(nb, want_nb)
+    assert len(nb) > n                                              # the case has plenty of neighbours
+
+
+def run_contacts(bodies, sid, kind, substeps, frames, pad=0.02):
+    polys = ob.polytopes_array(POLY_NAMES[kind])
+    want, want_masks, stats = bodies, [], []
+    for _ in range(frames):
+        want, m, st = ob.contacts_step(want, sid, polys, DT, substeps, pad, want_masks=True)
+        want_masks.append(m)
+        stats.append((st.n_pairs, st.n_touching, st.n_points))
+    got_masks, got_stats = [], []
+    with capi.World(mode=capi.MODE_CONTACTS, trace_contacts=True) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.set_contact_pad(pad)
+        w.upload(bodies, sid)
+        for _ in range(frames):
+            w.step(DT, substeps)
+            got_masks.append(w.contact_masks(substeps))
+            got_stats.append(w.contact_stats())
+        got = w.download()
+    return got, np.array(got_masks), got_stats, want, np.array(want_masks), stats
+
+
+def test_contact_pipeline_box_column_matches_oracle():
+    n = 6
+    bodies, sid = capi.scene_generate(capi.SCENE_BOXES, 1, n)
+    bodies[:, 34:38] = [1.0, 0.0, 0.0, 0.0]
+    bodies[:, 22:28] = 0.0
+    bodies[:, 31:33] = 0.0
+    bodies[:, 33] = np.arange(n) * 1.001
+    got, gm, gs, want, wm, ws = run_contacts(bodies, sid, capi.SCENE_BOXES, 20, 30)
+    assert gs == ws and np.array_equal(gm, wm)
+    assert bits_equal(got, want)
+    # the column is still standing: every box within 2 mm of its rest height, upright
+    np.testing.assert_allclose(got[:, 33], np.arange(n), atol=3e-3 * n)
+    assert np.abs(got[:, 35:38]).max() < 1e-2
+    assert ws[-1][1] == 20 * (n - 1)                                # every adjacent pair touches in every substep
+
+
+@pytest.mark.parametrize("kind,n,width", [(capi.SCENE_BOXES_DROP, 150, 4.0), (capi.SCENE_MIXED_DROP, 200, 2.5)])
+def test_contact_pipeline_pile_matches_oracle(kind, n, width):
+    bodies, sid = pile(kind, n, 8, width, 6.0)
+    got, gm, gs, want, wm, ws = run_contacts(bodies, sid, kind, 10, 40)
+    assert gs == ws                                                 # same pairs, touching pairs and point counts
+    assert np.array_equal(gm, wm)                                   # same ground-contact masks in every substep
+    assert bits_equal(got, want)
+    assert sum(s[1] for s in ws) > 100 and sum(s[2] for s in ws) > 200   # bodies really did collide
+
+
+def test_contacts_mode_without_overlaps_equals_the_reference_path():
+    """On a scene whose bounding spheres never overlap the extension must not change a single bit."""
+    verts, off = capi.scene_shapes(capi.SCENE_BOXES)
+    bodies, sid = capi.scene_generate(capi.SCENE_BOXES_DROP, 3, 500)
+    bodies[:, 31:33] *= 2.0                                         # 4 m pitch
+    want = bodies
+    for _ in range(5):
+        want, _ = ob.step_bodies(want, sid, verts, off, DT, 20, threads=8)
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(capi.SCENE_BOXES))
+        w.upload(bodies, sid)
+        for _ in range(5):
+            w.step(DT, 20)
+        assert w.contact_stats()[0] == 0
+        assert bits_equal(w.download(), want)
