@@ -84,8 +84,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--bodies", type=int, default=262144, help="bodies per GPU (weak scaling)")
     ap.add_argument("--substeps", type=int, default=20)
-    ap.add_argument("--scene", default="boxes-drop", choices=["boxes", "mixed", "boxes-drop", "mixed-drop"])
-    ap.add_argument("--mode", default="fused", choices=["fused", "substep"])
+    ap.add_argument("--scene", default="boxes-drop", choices=["boxes", "mixed", "boxes-drop", "mixed-drop", "stacks"])
+    ap.add_argument("--mode", default="fused", choices=["fused", "substep", "contacts"],
+                    help="contacts = EXTENSION (body-body contacts; not in the reference, parity unpinned)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,15 +125,18 @@ def main():
     from constraint_solver_amd.sharding import shard_range
 
     kind = {"boxes": capi.SCENE_BOXES, "mixed": capi.SCENE_MIXED, "boxes-drop": capi.SCENE_BOXES_DROP,
-            "mixed-drop": capi.SCENE_MIXED_DROP}[args.scene]
-    mode = capi.MODE_FUSED if args.mode == "fused" else capi.MODE_PER_SUBSTEP
+            "mixed-drop": capi.SCENE_MIXED_DROP, "stacks": capi.SCENE_BOX_STACKS}[args.scene]
+    mode = {"fused": capi.MODE_FUSED, "substep": capi.MODE_PER_SUBSTEP, "contacts": capi.MODE_CONTACTS}[args.mode]
     total = args.bodies * world_size
     first, count = shard_range(total, rank, world_size)
     verts, offsets = capi.scene_shapes(kind)
     bodies, shape_id = capi.scene_generate(kind, args.seed, total, first=first, count=count)
 
     world = capi.World(device=local_rank, mode=mode, block_size=args.block_size)
-    world.set_shapes(verts, offsets)
+    if mode == capi.MODE_CONTACTS:
+        world.set_polytopes(capi.scene_polytopes(kind))
+    else:
+        world.set_shapes(verts, offsets)
     world.upload(bodies, shape_id)                       # inputs resident in HBM before any timing
     # Run on an explicit torch stream so torch.cuda.Event (HIP events) brackets OUR launches; the
     # default stream's handle is 0, which the ABI reads as "use the world's own stream".
@@ -161,7 +165,7 @@ def main():
 
     result = None
     if rank == 0:
-        launches_per_step = 1 if mode == capi.MODE_FUSED else args.substeps
+        launches_per_step = 1 if mode == capi.MODE_FUSED else args.substeps   # contacts: 3 kernels per substep
         launch_s = device_ms * 1e-3 / (args.steps * launches_per_step)
         bytes_per_launch = capi.BYTES_PER_BODY_SUBSTEP * count   # 412 B x bodies, fused or not
         achieved = bytes_per_launch / launch_s / 1e9
@@ -180,7 +184,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d %s per GPU x %d substeps/frame, dt=1/60, ground contacts "
                                    "(reference semantics), seeded scene '%s'"
-                                   % (args.bodies, "unit boxes" if "boxes" in args.scene else "mixed convex polyhedra",
+                                   % (args.bodies, "mixed convex polyhedra" if "mixed" in args.scene else "unit boxes",
                                       args.substeps, args.scene),
                        "bodies_per_gpu": args.bodies, "bodies_total": total, "substeps": args.substeps,
                        "mode": args.mode, "sharding": "contiguous body-index ranges, no data-path collective"},
@@ -192,6 +196,13 @@ def main():
                          if mode == capi.MODE_FUSED else "one launch per substep: state round-trips HBM every substep"},
         }
         result["config"]["ground_contacts_per_body_after_run"] = len(world.contacts()) / max(count, 1)
+        if mode == capi.MODE_CONTACTS:
+            pairs, touching, points = world.contact_stats()
+            result["config"]["extension"] = ("body-body contacts: NOT in the reference (parity unpinned); roofline "
+                                             "fields price only the per-body state traffic")
+            result["config"]["neighbour_pairs"] = pairs
+            result["config"]["touching_pairs_per_substep"] = touching / max((args.steps + args.warmup) * args.substeps, 1)
+            result["config"]["manifold_points_per_substep"] = points / max((args.steps + args.warmup) * args.substeps, 1)
         if world_size == 1:
             # Informational, never `value`: the same frame when the boundary hands over HOST buffers
             # (AoS upload over PCIe -> step -> AoS download), as a literal per-frame drop-in would.
@@ -205,7 +216,7 @@ def main():
             result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": "body*substeps/s",
                                         "ms_per_frame": per_frame * 1e3,
                                         "what": "pageable host AoS upload + step + download every frame"}
-        if world_size == 1 and not args.no_cpu_baseline:
+        if world_size == 1 and not args.no_cpu_baseline and mode != capi.MODE_CONTACTS:
             state = world.download()
             result["cpu_baseline"] = cpu_baseline(state, shape_id, verts, offsets, args.substeps)
         print(json.dumps(result), flush=True)

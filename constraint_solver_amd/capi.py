@@ -284,7 +284,7 @@ def selftest_div_sqrt(a, b, device=0):
 
 
 # ---- host mirror (CPU set-up math; no GPU needed) -------------------------------
-SCENE_BOXES, SCENE_MIXED, SCENE_BOXES_DROP, SCENE_MIXED_DROP = 0, 1, 2, 3
+SCENE_BOXES, SCENE_MIXED, SCENE_BOXES_DROP, SCENE_MIXED_DROP, SCENE_BOX_STACKS = 0, 1, 2, 3, 4
 SHAPE_CUBE, SHAPE_TETRAHEDRON, SHAPE_ICOSAHEDRON = 0, 1, 2
 
 

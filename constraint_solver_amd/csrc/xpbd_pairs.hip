@@ -98,7 +98,7 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 
 __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                  Manifold *__restrict__ out, unsigned long long *__restrict__ stats)
+                                                  Manifold *__restrict__ out)
 {
     __shared__ PairLds s;
     const uint32_t p = blockIdx.x;
@@ -247,10 +247,6 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
             m->separation = ebest;
             m->p_ref[0][0] = pa.x, m->p_ref[0][1] = pa.y, m->p_ref[0][2] = pa.z;
             m->p_inc[0][0] = pb.x, m->p_inc[0][1] = pb.y, m->p_inc[0][2] = pb.z;
-            if (stats) {
-                atomicAdd(&stats[0], 1ull);
-                atomicAdd(&stats[1], 1ull);
-            }
         }
         return;
     }
@@ -325,9 +321,28 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     m->index_a = r ? iface : face_a;
     m->index_b = r ? face_b : iface;
     m->separation = face_best;
-    if (stats && n_out) {
-        atomicAdd(&stats[0], 1ull);
-        atomicAdd(&stats[1], (unsigned long long)n_out);
+}
+
+// stats[0] += pairs with contact points, stats[1] += contact points.  One atomic pair per BLOCK:
+// same-address atomics serialise at the memory side (~10 ns each), so they must not be per pair.
+__global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pairs, unsigned long long *__restrict__ stats)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t points = p < n_pairs ? m[p].n_points : 0u;
+    uint32_t touching = points ? 1u : 0u;
+    for (uint32_t off = 32; off; off >>= 1) {
+        points += __shfl_xor(points, off, 64);
+        touching += __shfl_xor(touching, off, 64);
+    }
+    __shared__ uint32_t part[2][4];
+    if ((threadIdx.x & 63u) == 0) {
+        part[0][threadIdx.x >> 6] = touching;
+        part[1][threadIdx.x >> 6] = points;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], (unsigned long long)(part[0][0] + part[0][1] + part[0][2] + part[0][3]));
+        atomicAdd(&stats[1], (unsigned long long)(part[1][0] + part[1][1] + part[1][2] + part[1][3]));
     }
 }
 
@@ -336,8 +351,11 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                             uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream)
 {
-    if (n_pairs)
-        hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, stats);
+    if (n_pairs) {
+        hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        if (stats)
+            hipLaunchKernelGGL(k_manifold_stats, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, out, n_pairs, stats);
+    }
     return hipGetLastError();
 }
 

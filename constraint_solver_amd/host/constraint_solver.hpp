@@ -443,6 +443,29 @@ class BatchWorld {
         static const double none[3] = {0, 0, 0};
         check(xpbd_world_set_shapes(w_, v.empty() ? none : v.data(), off.data(), (uint32_t)shapes.size()));
     }
+    // EXTENSION: full topology, needed by XPBD_MODE_CONTACTS (body-body contacts; not in the reference).
+    void set_polytopes(const std::vector<geometry::Polytope> &shapes)
+    {
+        std::vector<std::vector<double>> verts(shapes.size());
+        std::vector<std::vector<uint32_t>> edges(shapes.size()), foff(shapes.size()), fidx(shapes.size());
+        std::vector<xpbd_polytope> desc(shapes.size());
+        for (size_t s = 0; s < shapes.size(); ++s) {
+            const geometry::Polytope &p = shapes[s];
+            for (const Vec3 &x : p.vertices)
+                verts[s].insert(verts[s].end(), {x.x, x.y, x.z});
+            for (const auto &e : p.edges)
+                edges[s].insert(edges[s].end(), {e[0], e[1]});
+            foff[s].push_back(0);
+            for (const auto &f : p.faces) {
+                fidx[s].insert(fidx[s].end(), f.begin(), f.end());
+                foff[s].push_back((uint32_t)fidx[s].size());
+            }
+            desc[s] = xpbd_polytope{verts[s].data(), edges[s].data(), foff[s].data(), fidx[s].data(),
+                                    (uint32_t)p.vertices.size(), (uint32_t)p.edges.size(), (uint32_t)p.faces.size(), 0,
+                                    {p.centroid.x, p.centroid.y, p.centroid.z}};
+        }
+        check(xpbd_world_set_polytopes(w_, desc.data(), (uint32_t)desc.size()));
+    }
     void upload(const std::vector<rigid::Rigid> &bodies, const std::vector<uint32_t> &shape_id)
     {
         if (!shape_id.empty() && shape_id.size() != bodies.size())
@@ -501,8 +524,12 @@ enum Kind : uint32_t {
     BOXES = 0,      // config 1/2/4: unit cubes, density 1, z in [-0.05, 0.55): many start penetrating
     MIXED = 1,      // config 3: shape = i mod 3 over {cube, 0.5*tetrahedron, 0.5*icosahedron}, density 1
     BOXES_DROP = 2, // as BOXES but z in [0.4, 1.0): nobody penetrates at t=0, all land within 0.5 s and settle
-    MIXED_DROP = 3  // as MIXED with the DROP heights
+    MIXED_DROP = 3, // as MIXED with the DROP heights
+    // EXTENSION scene (body-body contacts, SURVEY 8d config 2/4 extension variant): columns of
+    // kStackHeight unit boxes, 1 mm gaps, upright and at rest; columns on a 2 m pitch grid.
+    BOX_STACKS = 4
 };
+constexpr uint32_t kStackHeight = 16;
 inline bool is_mixed(Kind k) { return (k & 1u) != 0; }
 inline bool is_drop(Kind k) { return (k & 2u) != 0; }
 
@@ -544,6 +571,13 @@ inline void generate(Kind kind, uint64_t seed, uint32_t grid_w, uint32_t first, 
         r.velocity = Vec3{rng.range(-1.0, 1.0), rng.range(-1.0, 1.0), rng.range(-1.0, 1.0)};
         r.angular_velocity = Vec3{rng.range(-4.0, 4.0), rng.range(-4.0, 4.0), rng.range(-4.0, 4.0)};
         r.external_force = Vec3{0.0, 0.0, -9.81 * mass[sid]};
+        if (kind == BOX_STACKS) {
+            const uint32_t column = i / kStackHeight, level = i % kStackHeight;
+            r.position = Vec3{2.0 * (double)(column % grid_w), 2.0 * (double)(column / grid_w), 1.001 * (double)level};
+            r.rotation = Quat{1.0, 0.0, 0.0, 0.0};
+            r.velocity = Vec3{0.0, 0.0, 0.0};
+            r.angular_velocity = Vec3{0.0, 0.0, 0.0};
+        }
         bodies[k] = r;
         shape_id[k] = sid;
     }

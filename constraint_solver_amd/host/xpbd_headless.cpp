@@ -2,8 +2,8 @@
 // renderer; the reference's app/renderer side, src/app.rs + src/renderer.rs, is
 // out of scope) on a seeded synthetic scene and reports body*substeps/s.
 //
-//   xpbd_headless --bodies 262144 --substeps 20 --frames 10 [--scene boxes|mixed|boxes-drop|mixed-drop]
-//                 [--seed 1] [--mode fused|substep] [--device 0] [--dump poses.bin]
+//   xpbd_headless --bodies 262144 --substeps 20 --frames 10 [--scene boxes|mixed|boxes-drop|mixed-drop|stacks]
+//                 [--seed 1] [--mode fused|substep|contacts] [--device 0] [--dump poses.bin]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -38,8 +38,8 @@ int main(int argc, char **argv)
         else if (const char *v = val("--warmup")) warmup = (uint32_t)std::strtoul(v, nullptr, 10);
         else if (const char *v = val("--seed")) seed = std::strtoull(v, nullptr, 10);
         else if (const char *v = val("--device")) device = std::atoi(v);
-        else if (const char *v = val("--scene")) kind = std::strcmp(v, "mixed") == 0 ? scene::MIXED : std::strcmp(v, "boxes-drop") == 0 ? scene::BOXES_DROP : std::strcmp(v, "mixed-drop") == 0 ? scene::MIXED_DROP : scene::BOXES;
-        else if (const char *v = val("--mode")) mode = std::strcmp(v, "substep") == 0 ? XPBD_MODE_PER_SUBSTEP : XPBD_MODE_FUSED;
+        else if (const char *v = val("--scene")) kind = std::strcmp(v, "mixed") == 0 ? scene::MIXED : std::strcmp(v, "boxes-drop") == 0 ? scene::BOXES_DROP : std::strcmp(v, "mixed-drop") == 0 ? scene::MIXED_DROP : std::strcmp(v, "stacks") == 0 ? scene::BOX_STACKS : scene::BOXES;
+        else if (const char *v = val("--mode")) mode = std::strcmp(v, "substep") == 0 ? XPBD_MODE_PER_SUBSTEP : std::strcmp(v, "contacts") == 0 ? XPBD_MODE_CONTACTS : XPBD_MODE_FUSED;
         else if (const char *v = val("--dump")) dump = v;
         else {
             std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -56,7 +56,10 @@ int main(int argc, char **argv)
         cfg.device = device;
         cfg.mode = mode;
         world::BatchWorld w(&cfg);
-        w.set_shapes(scene::shapes_of(kind));
+        if (mode == XPBD_MODE_CONTACTS)
+            w.set_polytopes(scene::shapes_of(kind)); // extension: body-body contacts
+        else
+            w.set_shapes(scene::shapes_of(kind));
         w.upload(state, shape_id);
 
         const double dt = 1.0 / 60.0; // FRAME_TIME, src/app.rs:15
@@ -73,7 +76,7 @@ int main(int argc, char **argv)
         const auto contacts = w.contacts();
         std::printf("{\"bodies\": %u, \"substeps\": %u, \"frames\": %u, \"mode\": \"%s\", \"seconds\": %.6f, "
                     "\"body_substeps_per_s\": %.4e, \"hbm_GBps_at_412B\": %.2f, \"contacts_last_substep\": %zu}\n",
-                    bodies, substeps, frames, mode == XPBD_MODE_FUSED ? "fused" : "substep", sec, rate,
+                    bodies, substeps, frames, mode == XPBD_MODE_FUSED ? "fused" : (mode == XPBD_MODE_CONTACTS ? "contacts" : "substep"), sec, rate,
                     mode == XPBD_MODE_FUSED ? 412.0 / substeps * rate / 1e9 : 412.0 * rate / 1e9, contacts.size());
         if (!dump.empty()) {
             FILE *fp = std::fopen(dump.c_str(), "wb");
