@@ -37,7 +37,8 @@ ABI_SYMBOLS = [
     "xpbd_world_download_contact_masks", "xpbd_world_set_stream", "xpbd_world_get_stream", "xpbd_world_set_mode",
     "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
     "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
-    "xpbd_world_download_neighbours",
+    "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
+    "xpbd_world_export_dynamic", "xpbd_world_import_dynamic",
 ]
 
 
@@ -115,6 +116,10 @@ def hip_lib():
         L.xpbd_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.xpbd_world_build_neighbours.argtypes = [C.c_void_p, C.c_double, _u32p]
         L.xpbd_world_download_neighbours.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint32]
+        L.xpbd_world_contacts_begin.argtypes = [C.c_void_p, C.c_double]
+        L.xpbd_world_contacts_substep.argtypes = [C.c_void_p, C.c_double]
+        L.xpbd_world_export_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_import_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _hip = L
     return _hip
 
@@ -258,6 +263,19 @@ class World:
         nb = np.zeros(max(n_entries.value, 1), dtype=np.uint32)
         _check(hip_lib().xpbd_world_download_neighbours(self._h, _u32(off), _u32(nb), nb.size))
         return off, nb[: n_entries.value]
+
+    def contacts_begin(self, dt):
+        _check(hip_lib().xpbd_world_contacts_begin(self._h, dt))
+
+    def contacts_substep(self, h):
+        _check(hip_lib().xpbd_world_contacts_substep(self._h, h))
+
+    def export_dynamic(self, dev_indices_ptr, n, dev_buf_ptr):
+        """Device pointers (e.g. torch tensor .data_ptr()): n uint32 indices, n x 13 doubles."""
+        _check(hip_lib().xpbd_world_export_dynamic(self._h, C.c_void_p(dev_indices_ptr), n, C.c_void_p(dev_buf_ptr)))
+
+    def import_dynamic(self, dev_indices_ptr, n, dev_buf_ptr):
+        _check(hip_lib().xpbd_world_import_dynamic(self._h, C.c_void_p(dev_indices_ptr), n, C.c_void_p(dev_buf_ptr)))
 
     def set_stream(self, stream_ptr):
         _check(hip_lib().xpbd_world_set_stream(self._h, C.c_void_p(stream_ptr)))

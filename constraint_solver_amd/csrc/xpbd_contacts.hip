@@ -431,6 +431,25 @@ __global__ void __launch_bounds__(kBlock) k_pair_solve_derive(BodyArrays b, doub
     store_dynamic(dyn_out, st, i, d);
 }
 
+// Halo exchange: one lane per (body, field); the buffer side is contiguous, the SoA side is a gather.
+__global__ void k_export_dynamic(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n, double *__restrict__ buf)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * kDynFields)
+        return;
+    const uint32_t k = t / kDynFields, f = t - k * kDynFields;
+    buf[t] = b.dyn[(size_t)f * b.stride + indices[k]];
+}
+
+__global__ void k_import_dynamic(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n, const double *__restrict__ buf)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * kDynFields)
+        return;
+    const uint32_t k = t / kDynFields, f = t - k * kDynFields;
+    b.dyn[(size_t)f * b.stride + indices[k]] = buf[t];
+}
+
 uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 } // namespace
@@ -522,6 +541,20 @@ hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double
 {
     if (b.n)
         hipLaunchKernelGGL(k_pair_solve_derive, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_dynamic(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *buf, hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_export_dynamic, dim3(blocks_for(n * kDynFields)), dim3(kBlock), 0, stream, b, indices, n, buf);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *buf, hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_import_dynamic, dim3(blocks_for(n * kDynFields)), dim3(kBlock), 0, stream, b, indices, n, buf);
     return hipGetLastError();
 }
 

@@ -217,6 +217,18 @@ int build_neighbours(xpbd_world *w, double dt)
     return XPBD_OK;
 }
 
+// One substep of the contact pipeline (neighbour lists must be current).
+int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_row)
+{
+    const xpbd::BodyArrays b = w->arrays();
+    const xpbd::ContactBuffers c = w->contact_buffers();
+    XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, trace_row, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
+    std::swap(w->dyn, w->dyn_alt);
+    return XPBD_OK;
+}
+
 // One xpbd_world_step in XPBD_MODE_CONTACTS (semantics: oracle/xpbd_pairs_oracle.h).
 int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_t *trace)
 {
@@ -224,14 +236,9 @@ int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_
         return fail(XPBD_E_INVALID, "XPBD_MODE_CONTACTS needs xpbd_world_set_polytopes");
     if (int rc = build_neighbours(w, dt))
         return rc;
-    for (uint32_t k = 0; k < substeps; ++k) {
-        const xpbd::BodyArrays b = w->arrays();
-        const xpbd::ContactBuffers c = w->contact_buffers();
-        XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, k, w->stream));
-        XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
-        XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
-        std::swap(w->dyn, w->dyn_alt);
-    }
+    for (uint32_t k = 0; k < substeps; ++k)
+        if (int rc = substep_contacts(w, h, trace, k))
+            return rc;
     return XPBD_OK;
 }
 
@@ -684,6 +691,51 @@ int xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts, d
     if (int rc = xpbd_world_step(cache.w, dt, substeps))
         return rc;
     return xpbd_world_download_bodies(cache.w, rigid, 1);
+}
+
+int xpbd_world_contacts_begin(xpbd_world *w, double dt)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_contacts_begin: NULL world");
+    if (w->mode != XPBD_MODE_CONTACTS || !w->has_topology)
+        return fail(XPBD_E_INVALID, "xpbd_world_contacts_begin: needs XPBD_MODE_CONTACTS and xpbd_world_set_polytopes");
+    if (int rc = bind_device(w))
+        return rc;
+    w->stepped = true;
+    return w->n ? build_neighbours(w, dt) : XPBD_OK;
+}
+
+int xpbd_world_contacts_substep(xpbd_world *w, double h)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_contacts_substep: NULL world");
+    if (w->mode != XPBD_MODE_CONTACTS || (w->n && !w->have_neighbours))
+        return fail(XPBD_E_INVALID, "xpbd_world_contacts_substep: call xpbd_world_contacts_begin first");
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    return substep_contacts(w, h, nullptr, 0);
+}
+
+int xpbd_world_export_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_buf)
+{
+    if (!w || (n && (!dev_indices || !dev_buf)))
+        return fail(XPBD_E_INVALID, "xpbd_world_export_dynamic: NULL argument");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_export_dynamic(w->arrays(), dev_indices, n, dev_buf, w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_buf)
+{
+    if (!w || (n && (!dev_indices || !dev_buf)))
+        return fail(XPBD_E_INVALID, "xpbd_world_import_dynamic: NULL argument");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_import_dynamic(w->arrays(), dev_indices, n, dev_buf, w->stream));
+    return XPBD_OK;
 }
 
 int xpbd_world_set_contact_pad(xpbd_world *w, double pad)

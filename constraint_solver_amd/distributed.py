@@ -1,0 +1,268 @@
+"""Multi-GPU form of the body-body contact EXTENSION: one process per GPU, halo bodies exchanged
+after every substep with one all-gather (RCCL over xGMI when the backend is nccl).
+
+Not part of the reference (which has no body-body contacts and no multi-device path); parity for
+it is "sharded run == single-device run, bit for bit", checked by tests/test_halo_gloo.py (CPU,
+gloo, oracle backend) and tests/test_gpu_pairs.py (GPU backend).
+
+Scheme
+------
+* Ownership: contiguous global index ranges (sharding.shard_range), as for the pinned path.
+* Every rank's world holds OWNED bodies plus GHOST copies of remote bodies that can reach an
+  owned body before the next re-plan; the local order is ascending global id, so every
+  neighbour list and every floating-point sum has the same order as on a single device.
+* A substep runs unchanged on owned + ghost bodies: a ghost's integrate + ground-contact stage
+  depends only on its own state, so it is recomputed locally (no exchange needed before the
+  SAT / pair solve); only the ghost's END-of-substep state is wrong locally (its neighbour set
+  is incomplete), and that is overwritten with the owner's result:
+      export owned boundary bodies (13 doubles each) -> all_gather -> import into the ghosts.
+* The halo is static between re-plans: `halo_margin` is how far any body may travel before
+  `replan()` must be called (re-gathers the whole state on the host; O(N) and not on the
+  per-substep path).
+"""
+import numpy as np
+
+from .sharding import shard_range
+
+DYN_FIELDS = 13
+# AoS (xpbd_rigid) columns of the 13 dynamic doubles in SoA field order: position, rotation, velocity, angular velocity
+DYN_AOS_COLUMNS = np.array([31, 32, 33, 34, 35, 36, 37, 22, 23, 24, 25, 26, 27])
+
+
+def bounding_spheres(bodies, shape_id, shape_radius, shape_centroid):
+    """Conservative world-space bounding spheres: centre = position + com, radius = r_shape + |centroid - com|."""
+    bodies = np.asarray(bodies)
+    com = bodies[:, 28:31]
+    centre = bodies[:, 31:34] + com
+    sid = np.asarray(shape_id, dtype=np.int64)
+    radius = np.asarray(shape_radius)[sid] + np.linalg.norm(np.asarray(shape_centroid)[sid] - com, axis=1)
+    return centre, radius
+
+
+class HaloPlan:
+    """Which remote bodies each rank mirrors, and where they sit in the all-gather buffer.
+    Deterministic function of the global sphere table, so every rank computes the same plan."""
+
+    def __init__(self, centre, radius, world_size, halo_margin, pad):
+        n = centre.shape[0]
+        self.n, self.world_size = n, world_size
+        edge = 2.0 * (float(radius.max()) + pad + halo_margin) if n else 1.0
+        cell = np.floor(centre / edge).astype(np.int64)
+        key = self._key(cell)
+        self.owned = [shard_range(n, r, world_size) for r in range(world_size)]
+        owner = np.zeros(n, dtype=np.int64)
+        for r, (first, count) in enumerate(self.owned):
+            owner[first:first + count] = r
+        offsets = np.array([(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=np.int64)
+        self.local_ids, ghost_sets = [], []
+        for r, (first, count) in enumerate(self.owned):
+            own_cells = np.unique(cell[first:first + count], axis=0)
+            reach = np.unique(self._key((own_cells[:, None, :] + offsets[None, :, :]).reshape(-1, 3)))
+            remote = np.nonzero((owner != r) & np.isin(key, reach))[0]
+            ghost_sets.append(remote)
+            self.local_ids.append(np.sort(np.concatenate([np.arange(first, first + count), remote])))
+        needed = np.zeros(n, dtype=bool)
+        for g in ghost_sets:
+            needed[g] = True
+        # boundary bodies of each rank = its owned bodies that some other rank mirrors, ascending
+        self.boundary = [np.nonzero(needed[f:f + c])[0] + f for (f, c) in self.owned]
+        self.capacity = max([len(b) for b in self.boundary] + [1])
+        self.ghosts = ghost_sets
+        self._owner = owner
+
+    @staticmethod
+    def _key(cell):
+        c = cell + (1 << 20)
+        return (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+
+    def rank_view(self, rank):
+        """Index arrays of one rank: local ids (global id per local slot), owned mask, local slots of its
+        boundary bodies, local slots of its ghosts and their rows in the gathered [W * capacity] buffer."""
+        ids = self.local_ids[rank]
+        first, count = self.owned[rank]
+        owned_mask = (ids >= first) & (ids < first + count)
+        boundary_slots = np.searchsorted(ids, self.boundary[rank])
+        ghost_ids = self.ghosts[rank]
+        ghost_slots = np.searchsorted(ids, ghost_ids)
+        rows = np.empty(len(ghost_ids), dtype=np.int64)
+        for k, g in enumerate(ghost_ids):
+            o = self._owner[g]
+            rows[k] = o * self.capacity + np.searchsorted(self.boundary[o], g)
+        return ids, owned_mask, boundary_slots, ghost_slots, rows
+
+
+class GpuBackend:
+    """capi.World in XPBD_MODE_CONTACTS; exchange buffers are torch CUDA tensors."""
+
+    def __init__(self, capi, polytopes, pad, device=0):
+        import torch
+        self.torch, self.capi = torch, capi
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(device)
+        self.stream = torch.cuda.Stream()          # non-default: handle 0 would mean "the world's own stream"
+        torch.cuda.set_stream(self.stream)
+        self.world = capi.World(device=device, mode=capi.MODE_CONTACTS)
+        self.world.set_polytopes(polytopes)
+        self.world.set_contact_pad(pad)
+        self.world.set_stream(self.stream.cuda_stream)
+
+    def upload(self, bodies, shape_id):
+        self.world.upload(bodies, shape_id)
+
+    def begin(self, dt):
+        self.world.contacts_begin(dt)
+
+    def substep(self, h):
+        self.world.contacts_substep(h)
+
+    def index_tensor(self, slots):
+        return self.torch.as_tensor(np.asarray(slots, dtype=np.int32), device=self.device)
+
+    def export(self, idx, out):
+        self.world.export_dynamic(idx.data_ptr(), idx.numel(), out.data_ptr())
+
+    def import_(self, idx, buf):
+        buf = buf.contiguous()
+        self.world.import_dynamic(idx.data_ptr(), idx.numel(), buf.data_ptr())
+        self._keep = buf                           # alive until the stream has consumed it
+
+    def empty(self, rows):
+        return self.torch.empty((rows, DYN_FIELDS), dtype=self.torch.float64, device=self.device)
+
+    def download(self):
+        return self.world.download()
+
+    def close(self):
+        self.world.close()
+
+
+class OracleBackend:
+    """CPU stand-in with the same interface, on oracle/xpbd_pairs_oracle.c (tests only)."""
+
+    def __init__(self, oracle_binding, poly_names, pad):
+        import ctypes
+        import torch
+        self.torch, self.C, self.ob = torch, ctypes, oracle_binding
+        self.L = oracle_binding._contacts_api()
+        P = ctypes.POINTER
+        self.L.op_contacts_begin.restype = ctypes.c_void_p
+        self.L.op_contacts_begin.argtypes = [ctypes.c_void_p, P(ctypes.c_uint32), ctypes.c_uint32,
+                                             P(oracle_binding.Polytope), ctypes.c_double, ctypes.c_double]
+        self.L.op_contacts_substep.restype = None
+        self.L.op_contacts_substep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.op_contacts_end.restype = None
+        self.L.op_contacts_end.argtypes = [ctypes.c_void_p]
+        self.polys = oracle_binding.polytopes_array(poly_names)
+        self.pad = pad
+        self.frame = None
+
+    def upload(self, bodies, shape_id):
+        self.bodies = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
+        self.sid = np.ascontiguousarray(shape_id, dtype=np.uint32)
+
+    def begin(self, dt):
+        self._end()
+        self.frame = self.L.op_contacts_begin(self.bodies.ctypes.data, self.sid.ctypes.data_as(self.C.POINTER(self.C.c_uint32)),
+                                              self.bodies.shape[0], self.polys, dt, self.pad)
+
+    def substep(self, h):
+        self.L.op_contacts_substep(self.frame, self.bodies.ctypes.data, h, None, None)
+
+    def index_tensor(self, slots):
+        return self.torch.as_tensor(np.asarray(slots, dtype=np.int64))
+
+    def export(self, idx, out):
+        out.copy_(self.torch.from_numpy(self.bodies[idx.numpy()][:, DYN_AOS_COLUMNS]))
+
+    def import_(self, idx, buf):
+        rows = idx.numpy()
+        self.bodies[rows[:, None], DYN_AOS_COLUMNS[None, :]] = buf.numpy()
+
+    def empty(self, rows):
+        return self.torch.empty((rows, DYN_FIELDS), dtype=self.torch.float64)
+
+    def download(self):
+        return self.bodies.copy()
+
+    def _end(self):
+        if self.frame:
+            self.L.op_contacts_end(self.frame)
+            self.frame = None
+
+    def close(self):
+        self._end()
+
+
+class ShardedContactWorld:
+    """One rank of an N-body world with body-body contacts sharded over `world_size` processes."""
+
+    def __init__(self, backend, rank, world_size, bodies_global, shape_id_global, shape_radius, shape_centroid,
+                 pad=0.02, halo_margin=0.5, group=None):
+        self.backend, self.rank, self.world_size, self.group = backend, rank, world_size, group
+        self.pad, self.halo_margin = pad, halo_margin
+        self.shape_radius, self.shape_centroid = shape_radius, shape_centroid
+        self.shape_id_global = np.asarray(shape_id_global, dtype=np.uint32)
+        self._plan(np.asarray(bodies_global, dtype=np.float64))
+
+    def _plan(self, bodies_global):
+        centre, radius = bounding_spheres(bodies_global, self.shape_id_global, self.shape_radius, self.shape_centroid)
+        self.plan = HaloPlan(centre, radius, self.world_size, self.halo_margin, self.pad)
+        ids, self.owned_mask, boundary_slots, ghost_slots, rows = self.plan.rank_view(self.rank)
+        self.local_ids = ids
+        b = self.backend
+        b.upload(bodies_global[ids], self.shape_id_global[ids])
+        self.boundary_idx = b.index_tensor(boundary_slots)
+        self.ghost_idx = b.index_tensor(ghost_slots)
+        self.ghost_rows = b.torch.as_tensor(rows, device=self.boundary_idx.device)
+        self.send = b.empty(self.plan.capacity)
+        self.n_boundary = len(boundary_slots)
+
+    def _exchange(self):
+        if self.world_size == 1:
+            return
+        import torch.distributed as dist
+        b = self.backend
+        if self.n_boundary:
+            b.export(self.boundary_idx, self.send[: self.n_boundary])
+        on_gloo = dist.get_backend(self.group) == "gloo"
+        send = self.send.cpu() if (on_gloo and self.send.is_cuda) else self.send
+        parts = [send.new_empty(send.shape) for _ in range(self.world_size)]
+        dist.all_gather(parts, send, group=self.group)               # halo all-gather (RCCL when nccl)
+        gathered = b.torch.cat(parts, dim=0)
+        if len(self.ghost_rows):
+            recv = gathered[self.ghost_rows.to(gathered.device)]
+            b.import_(self.ghost_idx, recv.to(self.send.device))
+
+    def step(self, dt, substeps):
+        """xpbd_world_step(dt, substeps) of the whole sharded world (lock step over ranks)."""
+        h = dt / float(substeps)
+        self.backend.begin(dt)
+        for _ in range(substeps):
+            self.backend.substep(h)
+            self._exchange()
+
+    def owned_state(self):
+        """(global ids, (k, 38) states) of the bodies this rank owns."""
+        state = self.backend.download()
+        return self.local_ids[self.owned_mask], state[self.owned_mask]
+
+    def gather_global(self):
+        """Full (N, 38) state on every rank (host-side; for tests, check-pointing and replan)."""
+        import torch
+        import torch.distributed as dist
+        ids, state = self.owned_state()
+        if self.world_size == 1:
+            return state
+        cap = max(c for _, c in self.plan.owned)
+        mine = torch.zeros(cap, 38, dtype=torch.float64)
+        mine[: len(ids)] = torch.from_numpy(state)
+        on_nccl = dist.get_backend(self.group) == "nccl"
+        if on_nccl:
+            mine = mine.cuda()
+        parts = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(parts, mine, group=self.group)
+        return np.concatenate([parts[r][: self.plan.owned[r][1]].cpu().numpy() for r in range(self.world_size)])
+
+    def replan(self):
+        """Re-select the halos from the current positions (call before any body has moved halo_margin)."""
+        self._plan(self.gather_global())

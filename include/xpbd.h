@@ -203,6 +203,18 @@ int  xpbd_world_contact_stats(xpbd_world *w, uint64_t out[3]);
 int  xpbd_world_build_neighbours(xpbd_world *w, double dt, uint32_t *n_entries_out);
 int  xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *neighbours, uint32_t cap);
 
+/* Split form of xpbd_world_step(w, dt, n) in XPBD_MODE_CONTACTS, for hosts that exchange halo
+ * bodies between substeps (multi-GPU):  begin(dt); n x { substep(dt / n); <exchange> }.
+ * begin runs the broadphase for the coming frame; substep is one substep of the pipeline. */
+int  xpbd_world_contacts_begin(xpbd_world *w, double dt);
+int  xpbd_world_contacts_substep(xpbd_world *w, double h);
+/* Halo exchange helpers.  dev_indices: DEVICE pointer to n body indices; dev_buf: DEVICE pointer
+ * to n x 13 doubles, body-major, in the SoA field order position[3] rotation{s,x,y,z}
+ * velocity[3] angular_velocity[3].  Both run asynchronously on the world's stream, so a
+ * collective enqueued on the same stream (or ordered after it) sees the data. */
+int  xpbd_world_export_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_buf);
+int  xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_buf);
+
 /* Diagnostics: quotient[i] = a[i] / b[i], root[i] = sqrt(a[i]) computed on the
  * device with the stepper's own code generation.  Bit-exact contact lists need
  * both to be correctly rounded; the parity tests check this against the host. */

@@ -315,33 +315,75 @@ static void accumulate_point(int self_is_inc, const o_rigid *inc, const o_rigid 
     acc->count++;
 }
 
-void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
-                      double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats)
+/* Broadphase result + scratch of one frame (split form of op_contacts_step for sharded hosts). */
+struct op_frame {
+    uint32_t n;
+    const uint32_t *shape_id;
+    const o_polytope *shapes;
+    uint32_t *off, *nb, *pair_first;
+    uint32_t n_pairs;
+    op_manifold *manifolds;
+    o_frame *past, *p1;
+    o_vec3 *past_pos;
+    o_rigid *next;
+};
+
+op_frame *op_contacts_begin(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                            double dt, double pad)
 {
-    uint32_t *off, *nb;
-    op_broadphase(bodies, shape_id, n, shapes, dt, pad, &off, &nb);
+    op_frame *f = (op_frame *)calloc(1, sizeof *f);
+    f->n = n;
+    f->shape_id = shape_id;
+    f->shapes = shapes;
+    op_broadphase(bodies, shape_id, n, shapes, dt, pad, &f->off, &f->nb);
     /* pair index of (i, j), i < j: pair_first[i] + rank of j among i's neighbours > i */
-    uint32_t *pair_first = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    f->pair_first = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 1));
     uint32_t n_pairs = 0;
     for (uint32_t i = 0; i < n; i++) {
-        pair_first[i] = n_pairs;
-        for (uint32_t k = off[i]; k < off[i + 1]; k++)
-            n_pairs += nb[k] > i;
+        f->pair_first[i] = n_pairs;
+        for (uint32_t k = f->off[i]; k < f->off[i + 1]; k++)
+            n_pairs += f->nb[k] > i;
     }
-    pair_first[n] = n_pairs;
-    op_manifold *manifolds = (op_manifold *)malloc(sizeof(op_manifold) * (n_pairs ? n_pairs : 1));
-    o_frame *past = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
-    o_frame *p1 = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
-    o_vec3 *past_pos = (o_vec3 *)malloc(sizeof(o_vec3) * (n ? n : 1));
-    o_rigid *next = (o_rigid *)malloc(sizeof(o_rigid) * (n ? n : 1));
-    if (stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->n_pairs = n_pairs;
-    }
-    const double h = dt / (double)substeps;
-    const double compliance = 1e-6 / (h * h);
+    f->pair_first[n] = n_pairs;
+    f->n_pairs = n_pairs;
+    f->manifolds = (op_manifold *)malloc(sizeof(op_manifold) * (n_pairs ? n_pairs : 1));
+    f->past = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
+    f->p1 = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
+    f->past_pos = (o_vec3 *)malloc(sizeof(o_vec3) * (n ? n : 1));
+    f->next = (o_rigid *)malloc(sizeof(o_rigid) * (n ? n : 1));
+    return f;
+}
 
-    for (uint32_t step = 0; step < substeps; step++) {
+uint64_t op_contacts_pair_count(const op_frame *f) { return f->n_pairs; }
+
+void op_contacts_end(op_frame *f)
+{
+    if (!f)
+        return;
+    free(f->off);
+    free(f->nb);
+    free(f->pair_first);
+    free(f->manifolds);
+    free(f->past);
+    free(f->p1);
+    free(f->past_pos);
+    free(f->next);
+    free(f);
+}
+
+/* One substep (steps 1-5 of the header comment).  masks_row: n entries or NULL. */
+void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks_row, op_contact_stats *stats)
+{
+    const uint32_t n = f->n;
+    const uint32_t *shape_id = f->shape_id;
+    const o_polytope *shapes = f->shapes;
+    uint32_t *off = f->off, *nb = f->nb, *pair_first = f->pair_first;
+    op_manifold *manifolds = f->manifolds;
+    o_frame *past = f->past, *p1 = f->p1;
+    o_vec3 *past_pos = f->past_pos;
+    o_rigid *next = f->next;
+    const double compliance = 1e-6 / (h * h);
+    {
         /* 1. integrate */
         for (uint32_t i = 0; i < n; i++) {
             past[i] = o_rigid_frame(&bodies[i]);
@@ -374,11 +416,11 @@ void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, con
             uint32_t cv[O_MAX_VERTS];
             uint32_t nc = o_ground(&bodies[i], past[i], p->vertices, p->n_vertices, cs, cv);
             o_solve(&bodies[i], cs, nc, h);
-            if (ground_masks) {
+            if (masks_row) {
                 uint32_t mask = 0;
                 for (uint32_t c = 0; c < nc; c++)
                     mask |= 1u << cv[c];
-                ground_masks[(size_t)step * n + i] = mask;
+                masks_row[i] = mask;
             }
         }
         /* 4. pair contacts, Jacobi with averaging; reads bodies[], writes next[] */
@@ -415,12 +457,18 @@ void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, con
             o_rigid_derive(&bodies[i], past_pos[i], past[i].rotation, h);
         }
     }
-    free(off);
-    free(nb);
-    free(pair_first);
-    free(manifolds);
-    free(past);
-    free(p1);
-    free(past_pos);
-    free(next);
+}
+
+void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                      double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats)
+{
+    op_frame *f = op_contacts_begin(bodies, shape_id, n, shapes, dt, pad);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_pairs = f->n_pairs;
+    }
+    const double h = dt / (double)substeps;
+    for (uint32_t step = 0; step < substeps; step++)
+        op_contacts_substep(f, bodies, h, ground_masks ? ground_masks + (size_t)step * n : NULL, stats);
+    op_contacts_end(f);
 }

@@ -85,6 +85,15 @@ typedef struct {
 void op_broadphase(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                    double dt, double pad, uint32_t **offsets_out, uint32_t **neighbours_out);
 
+/* Split form for hosts that overwrite halo bodies between substeps:
+ *   f = begin(bodies, .., dt, pad);  substeps x { substep(f, bodies, dt / substeps, ..); <exchange> };  end(f) */
+typedef struct op_frame op_frame;
+op_frame *op_contacts_begin(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
+                            double dt, double pad);
+uint64_t op_contacts_pair_count(const op_frame *f);
+void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks_row, op_contact_stats *stats);
+void op_contacts_end(op_frame *f);
+
 void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                       double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats);
 

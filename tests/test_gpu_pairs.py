@@ -197,3 +197,31 @@ def test_contacts_mode_without_overlaps_equals_the_reference_path():
             w.step(DT, 20)
         assert w.contact_stats()[0] == 0
         assert bits_equal(w.download(), want)
+
+
+def test_sharded_gpu_world_with_halo_exchange_equals_single_gpu(tmp_path):
+    """Two ranks (gloo rehearsal, both on this box's one GPU) stepping owned + ghost bodies with the HIP
+    pipeline and exchanging boundary bodies after every substep == one GPU world == the oracle."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    import halo_common as hc
+    kind, n, seed, width, substeps, frames, pad = capi.SCENE_BOXES_DROP, 200, 8, 4.0, 10, 8, 0.02
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(hc.worker, args=(2, port, str(tmp_path), "gpu", kind, n, seed, width, substeps, frames, pad, 4),
+             nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npy")
+    bodies, sid = hc.pile(capi, kind, n, seed, width, 6.0)
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.set_contact_pad(pad)
+        w.upload(bodies, sid)
+        for _ in range(frames):
+            w.step(DT, substeps)
+        single = w.download()
+    assert bits_equal(got, single)
+    assert bits_equal(got, hc.expected(ob, bodies, sid, kind, substeps, frames, pad))
