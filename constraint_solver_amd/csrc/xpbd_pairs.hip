@@ -15,7 +15,7 @@
 // (world space, and each into the other's local space); lanes then run in parallel over
 // faces x vertices, over the E_A x E_B edge pairs and over the incident body's faces, and combine
 // with __shfl_xor reductions that carry (value, index) so the reference's first/last tie-breaks
-// survive the parallel order.  Clipping (<= 4 planes x <= 8 points) runs on lane 0 out of LDS.
+// survive the parallel order.  Clipping runs one polygon vertex per lane with wave prefix sums.
 #include <cfloat>
 
 #include "xpbd_device.hpp"
@@ -275,16 +275,16 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     if (iface == kNone)
         iface = 0;
 
-    if (lane != 0)
-        return;
-
-    // Sutherland-Hodgman on lane 0: incident polygon clipped by the side planes of the reference face.
+    // Sutherland-Hodgman with ONE POLYGON VERTEX PER LANE (polygons have <= 16 vertices): every lane
+    // tests its edge (p0 -> p1) against the side plane, a wave prefix sum of the 0/1/2 points it emits
+    // gives their slots, so the output order is exactly that of the sequential algorithm.
     const uint32_t *rv = t.face_verts + t.face_start[dr.face0 + ref_face];
     const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
     const uint32_t *iv = t.face_verts + t.face_start[di.face0 + iface];
     uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
-    for (uint32_t q = 0; q < np; ++q)
-        st3(s.poly[0], q, ld3(s.world[r ^ 1u], iv[q]));
+    if (lane < np)
+        st3(s.poly[0], lane, ld3(s.world[r ^ 1u], iv[lane]));
+    __syncthreads();
     uint32_t cur = 0;
     for (uint32_t e = 0; e < nr && np > 0; ++e) {
         const Vec3 a = ld3(s.world[r], rv[e]), bnext = ld3(s.world[r], rv[(e + 1) % nr]);
@@ -292,30 +292,61 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
         Vec3 side = cross(bnext - a, ref_plane.normal);
         if (dot(side, c - a) > 0.0)
             side = -side;
-        uint32_t nd = 0;
-        for (uint32_t q = 0; q < np; ++q) {
-            const Vec3 p0 = ld3(s.poly[cur], q), p1 = ld3(s.poly[cur], (q + 1) % np);
-            const double d0 = dot(side, p0 - a), d1 = dot(side, p1 - a);
-            const bool in0 = d0 <= 0.0, in1 = d1 <= 0.0;
-            if (in0 && nd < 16)
-                st3(s.poly[cur ^ 1u], nd++, p0);
-            if (in0 != in1 && nd < 16)
-                st3(s.poly[cur ^ 1u], nd++, p0 + (p1 - p0) * (d0 / (d0 - d1)));
+        Vec3 p0{0.0, 0.0, 0.0}, p1{0.0, 0.0, 0.0};
+        double d0 = 0.0, d1 = 0.0;
+        bool in0 = false, crossing = false;
+        if (lane < np) {
+            p0 = ld3(s.poly[cur], lane);
+            p1 = ld3(s.poly[cur], lane + 1 == np ? 0u : lane + 1);
+            d0 = dot(side, p0 - a);
+            d1 = dot(side, p1 - a);
+            in0 = d0 <= 0.0;
+            crossing = in0 != (d1 <= 0.0);
         }
-        np = nd;
+        const uint32_t emit = (in0 ? 1u : 0u) + (crossing ? 1u : 0u);
+        uint32_t inc = emit;
+#pragma unroll
+        for (uint32_t d = 1; d < 16; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= d)
+                inc += up;
+        }
+        const uint32_t total = __shfl(inc, 15, 64);
+        uint32_t slot = inc - emit;
+        if (in0 && slot < 16)
+            st3(s.poly[cur ^ 1u], slot++, p0);
+        if (crossing && slot < 16)
+            st3(s.poly[cur ^ 1u], slot, p0 + (p1 - p0) * (d0 / (d0 - d1)));
+        np = total < 16 ? total : 16;
         cur ^= 1u;
+        __syncthreads();
     }
-    uint32_t n_out = 0;
-    for (uint32_t q = 0; q < np && n_out < kMaxManifoldPoints; ++q) {
-        const Vec3 pt = ld3(s.poly[cur], q);
-        const double d = distance(ref_plane, pt);
-        if (d >= 0.0)
-            continue;
-        const Vec3 on_ref = pt - d * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
-        m->p_inc[n_out][0] = pt.x, m->p_inc[n_out][1] = pt.y, m->p_inc[n_out][2] = pt.z;
-        m->p_ref[n_out][0] = on_ref.x, m->p_ref[n_out][1] = on_ref.y, m->p_ref[n_out][2] = on_ref.z;
-        ++n_out;
+    // every clipped point strictly below the reference plane is a contact, in polygon order
+    Vec3 pt{0.0, 0.0, 0.0};
+    double depth = 0.0;
+    bool keep = false;
+    if (lane < np) {
+        pt = ld3(s.poly[cur], lane);
+        depth = distance(ref_plane, pt);
+        keep = !(depth >= 0.0);
     }
+    uint32_t inc = keep ? 1u : 0u;
+#pragma unroll
+    for (uint32_t d = 1; d < 16; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if (lane >= d)
+            inc += up;
+    }
+    const uint32_t kept = __shfl(inc, 15, 64);
+    const uint32_t n_out = kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
+    if (keep && inc - 1 < kMaxManifoldPoints) {
+        const uint32_t at = inc - 1;
+        const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
+        m->p_inc[at][0] = pt.x, m->p_inc[at][1] = pt.y, m->p_inc[at][2] = pt.z;
+        m->p_ref[at][0] = on_ref.x, m->p_ref[at][1] = on_ref.y, m->p_ref[at][2] = on_ref.z;
+    }
+    if (lane != 0)
+        return;
     m->n_points = n_out;
     m->feature = r;
     m->index_a = r ? iface : face_a;
