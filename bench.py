@@ -255,6 +255,29 @@ def main():
             result["config"]["neighbour_pairs"] = pairs
             result["config"]["touching_pairs_per_substep"] = touching / max((args.steps + args.warmup) * args.substeps, 1)
             result["config"]["manifold_points_per_substep"] = points / max((args.steps + args.warmup) * args.substeps, 1)
+        if world_size == 1 and mode == capi.MODE_FUSED:
+            # The same kernel scheduled one launch per substep (state round-trips HBM every substep):
+            # the HBM-roofline-comparable form, measured in the same run on the same resident state.
+            frames = max(3, min(10, args.steps))
+            world.set_mode(capi.MODE_PER_SUBSTEP)
+            for _ in range(2):
+                world.step(FRAME_TIME, args.substeps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(frames):
+                world.step(FRAME_TIME, args.substeps)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            world.set_mode(capi.MODE_FUSED)
+            sub_s = e0.elapsed_time(e1) * 1e-3 / (frames * args.substeps)
+            tr = None
+            if os.path.exists(tfile):
+                tr = json.load(open(tfile)).get("substep_%d" % count, {}).get("bytes_per_launch")
+            result["roofline_unfused"] = {"bound": "hbm", "achieved": bytes_per_launch / sub_s / 1e9, "peak": HBM_PEAK_GBPS,
+                                          "unit": "GB/s", "frac": bytes_per_launch / sub_s / 1e9 / HBM_PEAK_GBPS,
+                                          "traffic": tr, "kernel": "k_step", "launch_us": sub_s * 1e6,
+                                          "body_substeps_per_s": count / sub_s,
+                                          "note": "XPBD_MODE_PER_SUBSTEP: one launch per substep, 412 B per body per launch"}
         if world_size == 1:
             # Informational, never `value`: the same frame when the boundary hands over HOST buffers
             # (AoS upload over PCIe -> step -> AoS download), as a literal per-frame drop-in would.

@@ -225,3 +225,58 @@ def test_sharded_gpu_world_with_halo_exchange_equals_single_gpu(tmp_path):
         single = w.download()
     assert bits_equal(got, single)
     assert bits_equal(got, hc.expected(ob, bodies, sid, kind, substeps, frames, pad))
+
+
+def test_contacts_mode_edge_cases():
+    polys = capi.scene_polytopes(capi.SCENE_BOXES)
+    verts, off = capi.scene_shapes(capi.SCENE_BOXES)
+    with capi.World(mode=capi.MODE_CONTACTS, trace_contacts=True) as w:
+        with pytest.raises(capi.XpbdError):
+            w.set_shapes(verts, off)
+            w.upload(np.zeros((0, 38)))
+            w.step(DT, 4)                                          # contacts mode without topology, but n == 0 is a no-op
+            one, sid = capi.scene_generate(capi.SCENE_BOXES, 1, 1)
+            w.upload(one, sid)
+            w.step(DT, 4)                                          # ... and with a body it is an error
+        w.set_polytopes(polys)
+        w.upload(np.zeros((0, 38)))
+        w.step(DT, 4)
+        assert w.download().shape == (0, 38) and w.contact_stats() == (0, 0, 0)
+        # a single body: no pairs, equals the reference path; masks are traced in contacts mode too
+        one, sid = capi.scene_generate(capi.SCENE_BOXES, 1, 1)
+        w.upload(one, sid)
+        w.step(DT, 20)
+        want, masks = ob.step_bodies(one, sid, verts, off, DT, 20, want_masks=True)
+        assert bits_equal(w.download(), want) and np.array_equal(w.contact_masks(20), masks)
+        assert np.array_equal(w.contacts(), ob.masks_to_contacts(masks[-1]))
+        # two coincident boxes (deep overlap, degenerate directions) must not fault and must match the oracle
+        two = np.repeat(one, 2, axis=0)
+        two[:, 33] = 2.0
+        two[1, 31] += 1e-9
+        w.upload(two, np.zeros(2, dtype=np.uint32))
+        w.step(DT, 5)
+        want2, _, _ = ob.contacts_step(two, None, ob.polytopes_array([("cube", 1.0)]), DT, 5, 0.02)
+        got2 = w.download()
+        nan = np.isnan(want2)
+        assert np.array_equal(np.isnan(got2), nan) and bits_equal(np.where(nan, 0.0, got2), np.where(nan, 0.0, want2))
+
+
+def test_switching_modes_on_one_world():
+    """fused -> contacts -> per-substep on the same resident bodies: each call has its own semantics."""
+    kind = capi.SCENE_BOXES_DROP
+    bodies, sid = pile(kind, 120, 4, 3.5, 5.0)
+    verts, off = capi.scene_shapes(kind)
+    polys = ob.polytopes_array(POLY_NAMES[kind])
+    want, _ = ob.step_bodies(bodies, sid, verts, off, DT, 10)                     # fused: bodies pass through each other
+    want, _, st = ob.contacts_step(want, sid, polys, DT, 10, 0.02)               # contacts
+    want, _ = ob.step_bodies(want, sid, verts, off, DT, 10)                       # per-substep, no pair contacts
+    with capi.World(mode=capi.MODE_FUSED) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.upload(bodies, sid)
+        w.step(DT, 10)
+        w.set_mode(capi.MODE_CONTACTS)
+        w.step(DT, 10)
+        assert w.contact_stats()[0] == st.n_pairs
+        w.set_mode(capi.MODE_PER_SUBSTEP)
+        w.step(DT, 10)
+        assert bits_equal(w.download(), want)
