@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pitch", type=float, default=2.0,
+                    help="grid pitch of the scene in metres (generator default 2.0); < 2 packs bodies so that they collide")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier/MAX reduction (gloo: rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
@@ -180,6 +182,8 @@ def main():
     first, count = shard_range(total, rank, world_size)
     verts, offsets = capi.scene_shapes(kind)
     bodies, shape_id = capi.scene_generate(kind, args.seed, total, first=first, count=count)
+    if args.pitch != 2.0:
+        bodies[:, 31:33] *= args.pitch / 2.0
 
     if mode == capi.MODE_CONTACTS and world_size > 1:
         return run_contacts_sharded(args, capi, kind, rank, local_rank, world_size)

@@ -10,7 +10,7 @@ namespace xpbd {
 struct ContactBuffers {
     // broadphase, per body
     double *centers;        // [3][stride] bounding-sphere centre (frame * centroid)
-    double *radius;         // [stride]    r_shape + |v| dt + pad
+    double *radius;         // [stride]    r_shape + min(|v| dt, r_shape) + pad
     int32_t *cell;          // [3][stride] grid cell of the centre
     uint32_t *key;          // [stride]    hash bucket of that cell
     unsigned long long *max_radius_bits; // [1]

@@ -113,7 +113,8 @@ __global__ void k_scan_add(uint32_t *__restrict__ data, uint32_t n, const uint32
 // ---------------------------------------------------------------------------------------------------
 // Broadphase
 // ---------------------------------------------------------------------------------------------------
-// Bounding sphere of every body: centre = frame * centroid, radius = r_shape + |v| dt + pad.
+// Bounding sphere of every body: centre = frame * centroid, radius = r_shape + min(|v| dt, r_shape) + pad.
+// The clamp keeps one runaway body from inflating the grid cell of everybody (cell edge = 2 * max radius).
 __global__ void k_bounds(BodyArrays b, PolytopeTables t, const double *__restrict__ shape_radius, double dt, double pad,
                          ContactBuffers c)
 {
@@ -124,7 +125,8 @@ __global__ void k_bounds(BodyArrays b, PolytopeTables t, const double *__restric
     const double *cc = t.centroids + 3 * (size_t)sid;
     const Vec3 centre = body_frame(b, i) * Vec3{cc[0], cc[1], cc[2]};
     const Vec3 vel = load3(b.dyn, D_VEL, b.stride, i);
-    const double r = shape_radius[sid] + length(vel) * dt + pad;
+    const double rs = shape_radius[sid], travel = length(vel) * dt;
+    const double r = rs + (travel < rs ? travel : rs) + pad;
     store3(c.centers, 0, b.stride, i, centre);
     c.radius[i] = r;
     if (r > 0.0 && r <= DBL_MAX) // positive finite doubles order like their bit patterns

@@ -191,7 +191,7 @@ int  xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pai
                             xpbd_manifold *out);
 
 /* XPBD_MODE_CONTACTS: per xpbd_world_step a sphere broadphase builds sorted neighbour lists
- * (sphere = centroid, r_shape + |v| dt + pad); per substep: integrate -> SAT of every neighbour
+ * (sphere = centroid, r_shape + min(|v| dt, r_shape) + pad); per substep: integrate -> SAT of every neighbour
  * pair -> ground contacts (reference path) -> pair contacts, Jacobi-averaged with a fixed
  * summation order -> derive.  Exact semantics: oracle/xpbd_pairs_oracle.h.  With no overlapping
  * spheres the result equals XPBD_MODE_PER_SUBSTEP bit for bit. */

@@ -247,7 +247,11 @@ void op_broadphase(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, 
     for (uint32_t i = 0; i < n; i++) {
         const o_polytope *p = &shapes[shape_id ? shape_id[i] : 0];
         c[i] = o_frame_mulv(o_rigid_frame(&bodies[i]), p->centroid);
-        r[i] = shape_radius(p) + o_magnitude(bodies[i].velocity) * dt + pad;
+        /* the velocity inflation is clamped at the shape's own radius: a body that travels further than
+         * its own size in one frame tunnels under discrete detection anyway, and an unclamped outlier
+         * would blow up every grid cell of the device broadphase */
+        double rs = shape_radius(p), travel = o_magnitude(bodies[i].velocity) * dt;
+        r[i] = rs + (travel < rs ? travel : rs) + pad;
     }
     uint32_t *off = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
     size_t cap = 16, cnt = 0;

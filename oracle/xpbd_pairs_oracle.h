@@ -57,7 +57,7 @@ void op_sat(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, 
  * N-body step with body-body contacts (extension; parity unpinned).
  *
  * Once per call (broadphase):  bounding sphere of body b = (frame_b * centroid,
- *   r_shape + |v_b| * dt + pad);  j is a neighbour of b iff the spheres overlap
+ *   r_shape + min(|v_b| * dt, r_shape) + pad);  j is a neighbour of b iff the spheres overlap
  *   (strict '<' on squared distances).  Neighbour lists are sorted by index.
  * Per substep (h = dt / substeps), for all bodies in lock step:
  *   1. past = pose; Rigid::integrate(h); P1 = Rigid::frame()            (src/solver.rs:7-10)
