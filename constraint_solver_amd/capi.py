@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
     "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
     "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
-    "xpbd_world_export_dynamic", "xpbd_world_import_dynamic",
+    "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_set_joints",
 ]
 
 
@@ -64,6 +64,9 @@ class PolytopeDesc(C.Structure):
                 ("centroid", C.c_double * 3)]
 
 
+# xpbd_joint as a numpy record (64 bytes)
+JOINT_DTYPE = np.dtype([("body_a", "<u4"), ("body_b", "<u4"), ("anchor_a", "<f8", (3,)), ("anchor_b", "<f8", (3,)),
+                        ("distance", "<f8")])
 MAX_MANIFOLD_POINTS = 8
 FEATURE_FACE_A, FEATURE_FACE_B, FEATURE_EDGES = 0, 1, 2
 # xpbd_manifold as a numpy record (408 bytes)
@@ -116,6 +119,7 @@ def hip_lib():
         L.xpbd_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.xpbd_world_build_neighbours.argtypes = [C.c_void_p, C.c_double, _u32p]
         L.xpbd_world_download_neighbours.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint32]
+        L.xpbd_world_set_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.xpbd_world_contacts_begin.argtypes = [C.c_void_p, C.c_double]
         L.xpbd_world_contacts_substep.argtypes = [C.c_void_p, C.c_double]
         L.xpbd_world_export_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -263,6 +267,11 @@ class World:
         nb = np.zeros(max(n_entries.value, 1), dtype=np.uint32)
         _check(hip_lib().xpbd_world_download_neighbours(self._h, _u32(off), _u32(nb), nb.size))
         return off, nb[: n_entries.value]
+
+    def set_joints(self, joints):
+        """joints: JOINT_DTYPE records naming bodies of the last upload (extension; XPBD_MODE_CONTACTS)."""
+        j = np.ascontiguousarray(joints, dtype=JOINT_DTYPE)
+        _check(hip_lib().xpbd_world_set_joints(self._h, j.ctypes.data if j.size else None, j.size))
 
     def contacts_begin(self, dt):
         _check(hip_lib().xpbd_world_contacts_begin(self._h, dt))

@@ -6,6 +6,13 @@
 
 namespace xpbd {
 
+// xpbd_joint, device copy.
+struct Joint {
+    uint32_t body_a, body_b;
+    double anchor_a[3], anchor_b[3];
+    double distance;
+};
+
 // Device buffers of the contact pipeline (owned by the world, sized by the host).
 struct ContactBuffers {
     // broadphase, per body
@@ -33,6 +40,10 @@ struct ContactBuffers {
     Manifold *manifolds;    // [n_pairs]
     unsigned long long *stats; // [2] touching pairs, manifold points (summed over substeps)
     uint32_t *scan_scratch; // block totals of the scans
+    // joints: CSR body -> incident joints (ascending joint index); joint_off is NULL when there are none
+    const Joint *joints;
+    const uint32_t *joint_off;   // [n + 1]
+    const uint32_t *joint_list;  // [2 * n_joints]
 };
 
 // ---- broadphase (once per step call) -------------------------------------------------------------

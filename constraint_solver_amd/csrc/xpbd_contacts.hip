@@ -421,6 +421,33 @@ __global__ void __launch_bounds__(kBlock) k_pair_solve_derive(BodyArrays b, doub
         }
     }
 
+    // joints of this body, ascending joint index (same accumulator: the "mixed-constraint" pass)
+    if (c.joint_off) {
+        for (uint32_t k = c.joint_off[i]; k < c.joint_off[i + 1]; ++k) {
+            const Joint &jt = c.joints[c.joint_list[k]];
+            const bool self_is_a = jt.body_a == i;
+            const PairBody other = load_pair_body(b, c, self_is_a ? jt.body_b : jt.body_a);
+            const PairBody &ja = self_is_a ? self : other;
+            const PairBody &jb = self_is_a ? other : self;
+            const Vec3 p_a = Frame{frame_origin(ja.pos, ja.rot, ja.com), ja.rot} * Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]};
+            const Vec3 p_b = Frame{frame_origin(jb.pos, jb.rot, jb.com), jb.rot} * Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]};
+            const Vec3 difference = p_b - p_a;
+            const double dist = length(difference);
+            if (dist == 0.0)
+                continue; // coincident points: the reference's direction() would be NaN (K6); nothing to correct
+            const Vec3 dir = difference * (1.0 / dist);
+            const double w = generalized_inverse_mass(ja, p_a, dir) + generalized_inverse_mass(jb, p_b, dir);
+            const double lambda = (dist - jt.distance) / (w + compliance);
+            const Vec3 point = self_is_a ? p_a : p_b;
+            const Vec3 impulse = self_is_a ? lambda * dir : (-lambda) * dir;
+            dpos = dpos + impulse * self.inv_mass;
+            const Vec3 arm = point - (self.pos + self.com);
+            const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
+            drot = drot + (0.5 * spin) * self.rot;
+            ++count;
+        }
+    }
+
     BodyDynamic d;
     d.pos = self.pos;
     d.rot = self.rot;

@@ -116,6 +116,8 @@ struct xpbd_world {
         cb_past_pos, cb_manifolds, cb_stats, cb_scan;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
+    DeviceBuffer jt_joints, jt_off, jt_list;
+    uint32_t n_joints = 0;
     xpbd::ContactBuffers contact_buffers() const
     {
         xpbd::ContactBuffers c{};
@@ -140,6 +142,9 @@ struct xpbd_world {
         c.manifolds = cb_manifolds.as<xpbd::Manifold>();
         c.stats = cb_stats.as<unsigned long long>();
         c.scan_scratch = cb_scan.as<uint32_t>();
+        c.joints = n_joints ? jt_joints.as<xpbd::Joint>() : nullptr;
+        c.joint_off = n_joints ? jt_off.as<uint32_t>() : nullptr;
+        c.joint_list = n_joints ? jt_list.as<uint32_t>() : nullptr;
         return c;
     }
 
@@ -333,7 +338,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_key, &w->cb_maxr, &w->cb_bucket_start, &w->cb_bucket_cursor, &w->cb_items,
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
-                            &w->cb_stats, &w->cb_scan})
+                            &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
@@ -506,6 +511,7 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     XPBD_HIP_TRY(w->dyn.reserve((size_t)xpbd::kDynFields * stride * 8));
     XPBD_HIP_TRY(w->dyn_alt.reserve((size_t)xpbd::kDynFields * stride * 8));
     w->have_neighbours = false;
+    w->n_joints = 0; // joints name bodies by index: a new upload invalidates them
     XPBD_HIP_TRY(w->stat.reserve((size_t)xpbd::kStatFields * stride * 8));
     XPBD_HIP_TRY(w->shape_id.reserve((size_t)stride * 4));
     XPBD_HIP_TRY(w->last_mask.reserve((size_t)stride * 4));
@@ -691,6 +697,45 @@ int xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts, d
     if (int rc = xpbd_world_step(cache.w, dt, substeps))
         return rc;
     return xpbd_world_download_bodies(cache.w, rigid, 1);
+}
+
+int xpbd_world_set_joints(xpbd_world *w, const xpbd_joint *joints, uint32_t n_joints)
+{
+    static_assert(sizeof(xpbd_joint) == sizeof(xpbd::Joint), "xpbd_joint must mirror xpbd::Joint");
+    if (!w || (n_joints && !joints))
+        return fail(XPBD_E_INVALID, "xpbd_world_set_joints: NULL argument");
+    std::vector<uint32_t> off((size_t)w->n + 2, 0), list((size_t)2 * n_joints);
+    for (uint32_t k = 0; k < n_joints; ++k) {
+        const xpbd_joint &j = joints[k];
+        if (j.body_a >= w->n || j.body_b >= w->n || j.body_a == j.body_b)
+            return fail(XPBD_E_INVALID, "xpbd_world_set_joints: joint %u links bodies %u and %u of %u", k, j.body_a,
+                        j.body_b, w->n);
+        if (!(j.distance >= 0.0) || !(j.distance <= 1.0e300))
+            return fail(XPBD_E_INVALID, "xpbd_world_set_joints: joint %u has distance %g", k, j.distance);
+        ++off[j.body_a + 1];
+        ++off[j.body_b + 1];
+    }
+    for (uint32_t i = 0; i < w->n; ++i)
+        off[i + 1] += off[i];
+    std::vector<uint32_t> cursor(off.begin(), off.end() - 1);
+    for (uint32_t k = 0; k < n_joints; ++k) { // ascending joint index inside every body's list
+        list[cursor[joints[k].body_a]++] = k;
+        list[cursor[joints[k].body_b]++] = k;
+    }
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    w->n_joints = 0;
+    if (n_joints == 0)
+        return XPBD_OK;
+    XPBD_HIP_TRY(w->jt_joints.reserve((size_t)n_joints * sizeof(xpbd::Joint)));
+    XPBD_HIP_TRY(w->jt_off.reserve((size_t)(w->n + 1) * 4));
+    XPBD_HIP_TRY(w->jt_list.reserve((size_t)2 * n_joints * 4));
+    XPBD_HIP_TRY(hipMemcpy(w->jt_joints.ptr, joints, (size_t)n_joints * sizeof(xpbd::Joint), hipMemcpyHostToDevice));
+    XPBD_HIP_TRY(hipMemcpy(w->jt_off.ptr, off.data(), (size_t)(w->n + 1) * 4, hipMemcpyHostToDevice));
+    XPBD_HIP_TRY(hipMemcpy(w->jt_list.ptr, list.data(), (size_t)2 * n_joints * 4, hipMemcpyHostToDevice));
+    w->n_joints = n_joints;
+    return XPBD_OK;
 }
 
 int xpbd_world_contacts_begin(xpbd_world *w, double dt)

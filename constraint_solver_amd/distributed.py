@@ -2,8 +2,8 @@
 after every substep with one all-gather (RCCL over xGMI when the backend is nccl).
 
 Not part of the reference (which has no body-body contacts and no multi-device path); parity for
-it is "sharded run == single-device run, bit for bit", checked by tests/test_halo_gloo.py (CPU,
-gloo, oracle backend) and tests/test_gpu_pairs.py (GPU backend).
+it is "sharded run == single-device run, bit for bit", checked by tests/test_halo_gloo.py (CPU, gloo,
+with tests/halo_common.OracleBackend standing in for the device) and tests/test_gpu_pairs.py (GpuBackend).
 
 Scheme
 ------
@@ -43,7 +43,7 @@ class HaloPlan:
     """Which remote bodies each rank mirrors, and where they sit in the all-gather buffer.
     Deterministic function of the global sphere table, so every rank computes the same plan."""
 
-    def __init__(self, centre, radius, world_size, halo_margin, pad):
+    def __init__(self, centre, radius, world_size, halo_margin, pad, joint_pairs=None):
         n = centre.shape[0]
         self.n, self.world_size = n, world_size
         edge = 2.0 * (float(radius.max()) + pad + halo_margin) if n else 1.0
@@ -59,6 +59,11 @@ class HaloPlan:
             own_cells = np.unique(cell[first:first + count], axis=0)
             reach = np.unique(self._key((own_cells[:, None, :] + offsets[None, :, :]).reshape(-1, 3)))
             remote = np.nonzero((owner != r) & np.isin(key, reach))[0]
+            if joint_pairs is not None and len(joint_pairs):
+                # a joint with an owned body needs its partner locally, however far away it is
+                a, b = joint_pairs[:, 0], joint_pairs[:, 1]
+                partners = np.concatenate([b[(owner[a] == r) & (owner[b] != r)], a[(owner[b] == r) & (owner[a] != r)]])
+                remote = np.union1d(remote, partners)
             ghost_sets.append(remote)
             self.local_ids.append(np.sort(np.concatenate([np.arange(first, first + count), remote])))
         needed = np.zeros(n, dtype=bool)
@@ -106,8 +111,10 @@ class GpuBackend:
         self.world.set_contact_pad(pad)
         self.world.set_stream(self.stream.cuda_stream)
 
-    def upload(self, bodies, shape_id):
+    def upload(self, bodies, shape_id, joints=None):
         self.world.upload(bodies, shape_id)
+        if joints is not None and len(joints):
+            self.world.set_joints(joints)
 
     def begin(self, dt):
         self.world.contacts_begin(dt)
@@ -136,81 +143,34 @@ class GpuBackend:
         self.world.close()
 
 
-class OracleBackend:
-    """CPU stand-in with the same interface, on oracle/xpbd_pairs_oracle.c (tests only)."""
-
-    def __init__(self, oracle_binding, poly_names, pad):
-        import ctypes
-        import torch
-        self.torch, self.C, self.ob = torch, ctypes, oracle_binding
-        self.L = oracle_binding._contacts_api()
-        P = ctypes.POINTER
-        self.L.op_contacts_begin.restype = ctypes.c_void_p
-        self.L.op_contacts_begin.argtypes = [ctypes.c_void_p, P(ctypes.c_uint32), ctypes.c_uint32,
-                                             P(oracle_binding.Polytope), ctypes.c_double, ctypes.c_double]
-        self.L.op_contacts_substep.restype = None
-        self.L.op_contacts_substep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
-        self.L.op_contacts_end.restype = None
-        self.L.op_contacts_end.argtypes = [ctypes.c_void_p]
-        self.polys = oracle_binding.polytopes_array(poly_names)
-        self.pad = pad
-        self.frame = None
-
-    def upload(self, bodies, shape_id):
-        self.bodies = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
-        self.sid = np.ascontiguousarray(shape_id, dtype=np.uint32)
-
-    def begin(self, dt):
-        self._end()
-        self.frame = self.L.op_contacts_begin(self.bodies.ctypes.data, self.sid.ctypes.data_as(self.C.POINTER(self.C.c_uint32)),
-                                              self.bodies.shape[0], self.polys, dt, self.pad)
-
-    def substep(self, h):
-        self.L.op_contacts_substep(self.frame, self.bodies.ctypes.data, h, None, None)
-
-    def index_tensor(self, slots):
-        return self.torch.as_tensor(np.asarray(slots, dtype=np.int64))
-
-    def export(self, idx, out):
-        out.copy_(self.torch.from_numpy(self.bodies[idx.numpy()][:, DYN_AOS_COLUMNS]))
-
-    def import_(self, idx, buf):
-        rows = idx.numpy()
-        self.bodies[rows[:, None], DYN_AOS_COLUMNS[None, :]] = buf.numpy()
-
-    def empty(self, rows):
-        return self.torch.empty((rows, DYN_FIELDS), dtype=self.torch.float64)
-
-    def download(self):
-        return self.bodies.copy()
-
-    def _end(self):
-        if self.frame:
-            self.L.op_contacts_end(self.frame)
-            self.frame = None
-
-    def close(self):
-        self._end()
-
-
 class ShardedContactWorld:
     """One rank of an N-body world with body-body contacts sharded over `world_size` processes."""
 
     def __init__(self, backend, rank, world_size, bodies_global, shape_id_global, shape_radius, shape_centroid,
-                 pad=0.02, halo_margin=0.5, group=None):
+                 pad=0.02, halo_margin=0.5, group=None, joints_global=None):
         self.backend, self.rank, self.world_size, self.group = backend, rank, world_size, group
         self.pad, self.halo_margin = pad, halo_margin
         self.shape_radius, self.shape_centroid = shape_radius, shape_centroid
         self.shape_id_global = np.asarray(shape_id_global, dtype=np.uint32)
+        self.joints_global = joints_global          # records with body_a / body_b as GLOBAL ids (capi.JOINT_DTYPE)
         self._plan(np.asarray(bodies_global, dtype=np.float64))
 
     def _plan(self, bodies_global):
         centre, radius = bounding_spheres(bodies_global, self.shape_id_global, self.shape_radius, self.shape_centroid)
-        self.plan = HaloPlan(centre, radius, self.world_size, self.halo_margin, self.pad)
+        jg = self.joints_global
+        pairs = None if jg is None or not len(jg) else np.stack([jg["body_a"], jg["body_b"]], axis=1).astype(np.int64)
+        self.plan = HaloPlan(centre, radius, self.world_size, self.halo_margin, self.pad, joint_pairs=pairs)
         ids, self.owned_mask, boundary_slots, ghost_slots, rows = self.plan.rank_view(self.rank)
         self.local_ids = ids
         b = self.backend
-        b.upload(bodies_global[ids], self.shape_id_global[ids])
+        local_joints = None
+        if pairs is not None:
+            # joints whose two bodies are both present here, in global joint order, re-indexed to local slots
+            present = np.isin(pairs[:, 0], ids) & np.isin(pairs[:, 1], ids)
+            local_joints = jg[present].copy()
+            local_joints["body_a"] = np.searchsorted(ids, pairs[present, 0])
+            local_joints["body_b"] = np.searchsorted(ids, pairs[present, 1])
+        b.upload(bodies_global[ids], self.shape_id_global[ids], local_joints)
         self.boundary_idx = b.index_tensor(boundary_slots)
         self.ghost_idx = b.index_tensor(ghost_slots)
         self.ghost_rows = b.torch.as_tensor(rows, device=self.boundary_idx.device)

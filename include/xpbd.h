@@ -203,6 +203,20 @@ int  xpbd_world_contact_stats(xpbd_world *w, uint64_t out[3]);
 int  xpbd_world_build_neighbours(xpbd_world *w, double dt, uint32_t *n_entries_out);
 int  xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *neighbours, uint32_t cap);
 
+/* Joints (EXTENSION; the reference has no joint type, only the unused `distance`
+ * field of Constraint, src/constraint.rs:9).  A joint keeps |frame_b * anchor_b - frame_a * anchor_a|
+ * at `distance` (anchors in object space, the space of the shape vertices).  distance = 0 is a ball
+ * joint; a hinge is two ball joints on its axis.  Joints are projected in XPBD_MODE_CONTACTS together
+ * with the body-body contacts (same Jacobi pass, after a body's contacts, ascending joint index).
+ * Body indices refer to the bodies uploaded last; uploading bodies again clears the joints. */
+typedef struct xpbd_joint {
+    uint32_t body_a, body_b;
+    double   anchor_a[3];
+    double   anchor_b[3];
+    double   distance;
+} xpbd_joint;
+int  xpbd_world_set_joints(xpbd_world *w, const xpbd_joint *joints, uint32_t n_joints);
+
 /* Split form of xpbd_world_step(w, dt, n) in XPBD_MODE_CONTACTS, for hosts that exchange halo
  * bodies between substeps (multi-GPU):  begin(dt); n x { substep(dt / n); <exchange> }.
  * begin runs the broadphase for the coming frame; substep is one substep of the pipeline. */

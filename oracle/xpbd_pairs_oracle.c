@@ -330,7 +330,39 @@ struct op_frame {
     o_frame *past, *p1;
     o_vec3 *past_pos;
     o_rigid *next;
+    const op_joint *joints;
+    uint32_t n_joints;
 };
+
+void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_joints)
+{
+    f->joints = joints;
+    f->n_joints = n_joints;
+}
+
+/* One joint seen from body `self_is_a ? a : b` (poses after the ground contacts). */
+static void accumulate_joint(int self_is_a, const o_rigid *a, const o_rigid *b, const op_joint *j, double compliance,
+                             pair_accum *acc)
+{
+    o_vec3 p_a = o_frame_mulv(o_rigid_frame(a), (o_vec3){ j->anchor_a[0], j->anchor_a[1], j->anchor_a[2] });
+    o_vec3 p_b = o_frame_mulv(o_rigid_frame(b), (o_vec3){ j->anchor_b[0], j->anchor_b[1], j->anchor_b[2] });
+    o_vec3 difference = o_sub(p_b, p_a);
+    double distance = o_magnitude(difference);
+    if (distance == 0.0)
+        return;
+    o_vec3 dir = o_scale(difference, 1.0 / distance);
+    double w = generalized_inverse_mass(a, p_a, dir) + generalized_inverse_mass(b, p_b, dir);
+    double lambda = (distance - j->distance) / (w + compliance);
+
+    const o_rigid *self = self_is_a ? a : b;
+    o_vec3 point = self_is_a ? p_a : p_b;
+    o_vec3 impulse = self_is_a ? o_lscale(lambda, dir) : o_lscale(-lambda, dir);
+    acc->dpos = o_add(acc->dpos, o_scale(impulse, self->inverse_mass));
+    o_vec3 arm = o_sub(point, o_add(self->position, self->center_of_mass));
+    o_quat spin = { 0.0, o_cross(o_mat3_mulv(self->inverse_inertia, arm), impulse) };
+    acc->drot = o_qadd(acc->drot, o_qmul(o_qlscale(0.5, spin), self->rotation));
+    acc->count++;
+}
 
 op_frame *op_contacts_begin(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                             double dt, double pad)
@@ -446,6 +478,11 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
                 for (uint32_t pt = 0; pt < m->n_points; pt++)
                     accumulate_point(inc == b, &bodies[inc], &bodies[ref], p1[inc], past[inc], p1[ref], past[ref],
                                      m->p_inc[pt], m->p_ref[pt], compliance, &acc);
+            }
+            for (uint32_t jn = 0; jn < f->n_joints; jn++) { /* ascending joint index */
+                const op_joint *j = &f->joints[jn];
+                if (j->body_a == b || j->body_b == b)
+                    accumulate_joint(j->body_a == b, &bodies[j->body_a], &bodies[j->body_b], j, compliance, &acc);
             }
             next[b] = bodies[b];
             if (acc.count) {

@@ -94,6 +94,22 @@ uint64_t op_contacts_pair_count(const op_frame *f);
 void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks_row, op_contact_stats *stats);
 void op_contacts_end(op_frame *f);
 
+/* Joints (extension; the reference has no joint type, only the unused `distance` field of
+ * Constraint, src/constraint.rs:9).  A joint keeps |frame_b * anchor_b - frame_a * anchor_a| at
+ * `distance`; anchors are in object space (the space of the shape vertices).  distance = 0 is a ball
+ * joint, a hinge is two ball joints on the axis.  Joints are projected in the Jacobi pass of step 4,
+ * after the body's pair contacts, in ascending joint index, with the reference's constraint math:
+ * contacts = (p_a, p_b), lambda = (|p_b - p_a| - distance) / (w_a + w_b + compliance), +lambda*dir on
+ * a at p_a, -lambda*dir on b at p_b.  A joint whose points coincide exactly is skipped (the
+ * reference's direction() would be NaN, cf. K6). */
+typedef struct {
+    uint32_t body_a, body_b;
+    double anchor_a[3], anchor_b[3];
+    double distance;
+} op_joint;
+/* Must be called between begin and the first substep; `joints` must outlive the frame. */
+void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_joints);
+
 void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                       double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats);
 

@@ -9,6 +9,73 @@ POLY_NAMES = {0: [("cube", 1.0)], 2: [("cube", 1.0)],
               3: [("cube", 1.0), ("tetrahedron", 0.5), ("icosahedron", 0.5)]}
 
 
+DYN_FIELDS = 13
+DYN_AOS_COLUMNS = np.array([31, 32, 33, 34, 35, 36, 37, 22, 23, 24, 25, 26, 27])
+
+
+class OracleBackend:
+    """CPU stand-in for distributed.GpuBackend (same interface) on oracle/xpbd_pairs_oracle.c."""
+
+    def __init__(self, oracle_binding, poly_names, pad):
+        import ctypes
+        import torch
+        self.torch, self.C, self.ob = torch, ctypes, oracle_binding
+        self.L = oracle_binding._contacts_api()
+        P = ctypes.POINTER
+        self.L.op_contacts_begin.restype = ctypes.c_void_p
+        self.L.op_contacts_begin.argtypes = [ctypes.c_void_p, P(ctypes.c_uint32), ctypes.c_uint32,
+                                             P(oracle_binding.Polytope), ctypes.c_double, ctypes.c_double]
+        self.L.op_contacts_substep.restype = None
+        self.L.op_contacts_substep.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.op_contacts_end.restype = None
+        self.L.op_contacts_end.argtypes = [ctypes.c_void_p]
+        self.polys = oracle_binding.polytopes_array(poly_names)
+        self.pad = pad
+        self.frame = None
+        self.joints = None
+
+    def upload(self, bodies, shape_id, joints=None):
+        self.bodies = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
+        self.sid = np.ascontiguousarray(shape_id, dtype=np.uint32)
+        self.joints = None if joints is None or not len(joints) else np.ascontiguousarray(joints)
+
+    def begin(self, dt):
+        self._end()
+        self.frame = self.L.op_contacts_begin(self.bodies.ctypes.data, self.sid.ctypes.data_as(self.C.POINTER(self.C.c_uint32)),
+                                              self.bodies.shape[0], self.polys, dt, self.pad)
+        if self.joints is not None:
+            self.L.op_contacts_attach_joints.restype = None
+            self.L.op_contacts_attach_joints.argtypes = [self.C.c_void_p, self.C.c_void_p, self.C.c_uint32]
+            self.L.op_contacts_attach_joints(self.frame, self.joints.ctypes.data, self.joints.size)
+
+    def substep(self, h):
+        self.L.op_contacts_substep(self.frame, self.bodies.ctypes.data, h, None, None)
+
+    def index_tensor(self, slots):
+        return self.torch.as_tensor(np.asarray(slots, dtype=np.int64))
+
+    def export(self, idx, out):
+        out.copy_(self.torch.from_numpy(self.bodies[idx.numpy()][:, DYN_AOS_COLUMNS]))
+
+    def import_(self, idx, buf):
+        rows = idx.numpy()
+        self.bodies[rows[:, None], DYN_AOS_COLUMNS[None, :]] = buf.numpy()
+
+    def empty(self, rows):
+        return self.torch.empty((rows, DYN_FIELDS), dtype=self.torch.float64)
+
+    def download(self):
+        return self.bodies.copy()
+
+    def _end(self):
+        if self.frame:
+            self.L.op_contacts_end(self.frame)
+            self.frame = None
+
+    def close(self):
+        self._end()
+
+
 def pile(capi, kind, n, seed, width, height):
     rng = np.random.default_rng(seed)
     bodies, sid = capi.scene_generate(kind, seed, n)
@@ -25,22 +92,35 @@ def shape_tables(capi, kind):
     return polys, radius, centroid
 
 
-def expected(ob, bodies, sid, kind, substeps, frames, pad):
+def chain_joints(capi, n, every=3):
+    """Distance joints between body k and k + every (so they cross shard boundaries), face-centre anchors."""
+    a = np.arange(0, n - every, 2)
+    j = np.zeros(len(a), dtype=capi.JOINT_DTYPE)
+    j["body_a"], j["body_b"] = a, a + every
+    j["anchor_a"], j["anchor_b"], j["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], 1.5
+    return j
+
+
+def expected(ob, bodies, sid, kind, substeps, frames, pad, joints=None):
     polys = ob.polytopes_array(POLY_NAMES[kind])
     want = bodies
     for _ in range(frames):
-        want, _, _ = ob.contacts_step(want, sid, polys, DT, substeps, pad)
+        if joints is None:
+            want, _, _ = ob.contacts_step(want, sid, polys, DT, substeps, pad)
+        else:
+            want = ob.contacts_step_joints(want, sid, polys, joints, DT, substeps, pad)
     return want
 
 
-def worker(rank, world_size, port, out_dir, backend_name, kind, n, seed, width, substeps, frames, pad, replan_at):
+def worker(rank, world_size, port, out_dir, backend_name, kind, n, seed, width, substeps, frames, pad, replan_at,
+           with_joints=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [here, os.path.dirname(here)]
     import torch.distributed as dist
     from constraint_solver_amd import capi
-    from constraint_solver_amd.distributed import GpuBackend, OracleBackend, ShardedContactWorld
+    from constraint_solver_amd.distributed import GpuBackend, ShardedContactWorld
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
         bodies, sid = pile(capi, kind, n, seed, width, 6.0)
@@ -50,7 +130,9 @@ def worker(rank, world_size, port, out_dir, backend_name, kind, n, seed, width, 
         else:
             import oracle_binding as ob
             backend = OracleBackend(ob, POLY_NAMES[kind], pad)
-        world = ShardedContactWorld(backend, rank, world_size, bodies, sid, radius, centroid, pad=pad, halo_margin=0.75)
+        joints = chain_joints(capi, n) if with_joints else None
+        world = ShardedContactWorld(backend, rank, world_size, bodies, sid, radius, centroid, pad=pad, halo_margin=0.75,
+                                    joints_global=joints)
         assert sum(len(g) for g in world.plan.ghosts) > 0         # the case does have halos
         for f in range(frames):
             if f == replan_at:

@@ -259,3 +259,40 @@ def broadphase(bodies, shape_id, polys, dt, pad):
     libc.free(off)
     libc.free(nb)
     return offsets, neigh
+
+
+class Joint(C.Structure):
+    _fields_ = [("body_a", C.c_uint32), ("body_b", C.c_uint32), ("anchor_a", C.c_double * 3), ("anchor_b", C.c_double * 3),
+                ("distance", C.c_double)]
+
+
+def _frames_api():
+    L = _contacts_api()
+    if not hasattr(L, "_frames_ready"):
+        P = C.POINTER
+        L.op_contacts_begin.restype = C.c_void_p
+        L.op_contacts_begin.argtypes = [C.c_void_p, P(C.c_uint32), C.c_uint32, P(Polytope), C.c_double, C.c_double]
+        L.op_contacts_attach_joints.restype = None
+        L.op_contacts_attach_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.op_contacts_substep.restype = None
+        L.op_contacts_substep.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        L.op_contacts_end.restype = None
+        L.op_contacts_end.argtypes = [C.c_void_p]
+        L._frames_ready = True
+    return L
+
+
+def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad):
+    """One frame of op_contacts_* with joints (numpy records with the layout of `Joint`)."""
+    L = _frames_api()
+    b = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
+    n = b.shape[0]
+    sid = np.ascontiguousarray(shape_id if shape_id is not None else np.zeros(n), dtype=np.uint32)
+    j = np.ascontiguousarray(joints)
+    assert j.dtype.itemsize == C.sizeof(Joint)
+    f = L.op_contacts_begin(b.ctypes.data, sid.ctypes.data_as(C.POINTER(C.c_uint32)), n, polys, dt, pad)
+    L.op_contacts_attach_joints(f, j.ctypes.data if j.size else None, j.size)
+    for _ in range(substeps):
+        L.op_contacts_substep(f, b.ctypes.data, dt / substeps, None, None)
+    L.op_contacts_end(f)
+    return b

@@ -280,3 +280,59 @@ def test_switching_modes_on_one_world():
         w.set_mode(capi.MODE_PER_SUBSTEP)
         w.step(DT, 10)
         assert bits_equal(w.download(), want)
+
+
+# ------------------------------------------------------------------------------------------------
+# Joints (extension)
+# ------------------------------------------------------------------------------------------------
+def test_joints_with_contacts_match_oracle():
+    import halo_common as hc
+    kind, n = capi.SCENE_BOXES_DROP, 160
+    bodies, sid = pile(kind, n, 6, 4.0, 6.0)
+    joints = hc.chain_joints(capi, n)
+    hinge = np.zeros(2, dtype=capi.JOINT_DTYPE)                     # a hinge = two ball joints on the axis
+    hinge["body_a"], hinge["body_b"] = 1, 2
+    hinge["anchor_a"] = [[1.0, 0.0, 0.5], [1.0, 1.0, 0.5]]
+    hinge["anchor_b"] = [[0.0, 0.0, 0.5], [0.0, 1.0, 0.5]]
+    joints = np.concatenate([joints, hinge])
+    want = hc.expected(ob, bodies, sid, kind, 10, 30, 0.02, joints)
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.upload(bodies, sid)
+        w.set_joints(joints)
+        for _ in range(30):
+            w.step(DT, 10)
+        got = w.download()
+        assert bits_equal(got, want)
+        # the joints did something: without them the result differs
+        w.upload(bodies, sid)                                       # clears the joints
+        for _ in range(30):
+            w.step(DT, 10)
+        assert not bits_equal(w.download(), want)
+        bad = joints[:1].copy()
+        bad["body_b"] = bad["body_a"]
+        with pytest.raises(capi.XpbdError):
+            w.set_joints(bad)
+        bad["body_b"] = n + 5
+        with pytest.raises(capi.XpbdError):
+            w.set_joints(bad)
+    d = np.linalg.norm((got[joints["body_b"][:-2], 31:34]) - (got[joints["body_a"][:-2], 31:34]), axis=1)
+    assert np.abs(d - 1.5).max() < 0.2                              # chained boxes stay near their rest distance
+
+
+def test_sharded_gpu_world_with_joints_equals_single_gpu(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    import halo_common as hc
+    kind, n, seed, width, substeps, frames, pad = capi.SCENE_BOXES_DROP, 120, 8, 3.5, 8, 6, 0.02
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(hc.worker, args=(2, port, str(tmp_path), "gpu", kind, n, seed, width, substeps, frames, pad, 3, True),
+             nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npy")
+    bodies, sid = hc.pile(capi, kind, n, seed, width, 6.0)
+    assert bits_equal(got, hc.expected(ob, bodies, sid, kind, substeps, frames, pad, hc.chain_joints(capi, n)))

@@ -22,13 +22,15 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("world_size,kind,n,replan_at", [(2, capi.SCENE_BOXES_DROP, 90, -1), (3, capi.SCENE_MIXED_DROP, 120, 3)])
-def test_sharded_oracle_run_equals_single_process(tmp_path, world_size, kind, n, replan_at):
+@pytest.mark.parametrize("world_size,kind,n,replan_at,joints", [(2, capi.SCENE_BOXES_DROP, 90, -1, False),
+                                                                (3, capi.SCENE_MIXED_DROP, 120, 3, False),
+                                                                (2, capi.SCENE_BOXES_DROP, 80, 2, True)])
+def test_sharded_oracle_run_equals_single_process(tmp_path, world_size, kind, n, replan_at, joints):
     seed, width, substeps, frames, pad = 8, 3.0, 8, 6, 0.02
     mp.spawn(hc.worker, args=(world_size, free_port(), str(tmp_path), "oracle", kind, n, seed, width, substeps, frames, pad,
-                              replan_at), nprocs=world_size, join=True)
+                              replan_at, joints), nprocs=world_size, join=True)
     bodies, sid = hc.pile(capi, kind, n, seed, width, 6.0)
-    want = hc.expected(ob, bodies, sid, kind, substeps, frames, pad)
+    want = hc.expected(ob, bodies, sid, kind, substeps, frames, pad, hc.chain_joints(capi, n) if joints else None)
     got = np.load(tmp_path / "sharded.npy")
     assert bits_equal(got, want)
 
