@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--joints", type=int, default=0,
+                    help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
     ap.add_argument("--pitch", type=float, default=2.0,
                     help="grid pitch of the scene in metres (generator default 2.0); < 2 packs bodies so that they collide")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -194,6 +196,15 @@ def main():
     else:
         world.set_shapes(verts, offsets)
     world.upload(bodies, shape_id)                       # inputs resident in HBM before any timing
+    if args.joints and mode == capi.MODE_CONTACTS:
+        # BASELINE configs[4] (extension): chains of 5 bodies, 4 distance joints each, centre to centre at the pitch
+        k = np.arange(args.joints)
+        a = (k // 4) * 5 + (k % 4)
+        a = a[a + 1 < count]
+        joints = np.zeros(len(a), dtype=capi.JOINT_DTYPE)
+        joints["body_a"], joints["body_b"] = a, a + 1
+        joints["anchor_a"], joints["anchor_b"], joints["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], args.pitch
+        world.set_joints(joints)
     # Run on an explicit torch stream so torch.cuda.Event (HIP events) brackets OUR launches; the
     # default stream's handle is 0, which the ABI reads as "use the world's own stream".
     stream = torch.cuda.Stream()
@@ -256,6 +267,7 @@ def main():
             pairs, touching, points = world.contact_stats()
             result["config"]["extension"] = ("body-body contacts: NOT in the reference (parity unpinned); roofline "
                                              "fields price only the per-body state traffic")
+            result["config"]["joints"] = args.joints
             result["config"]["neighbour_pairs"] = pairs
             result["config"]["touching_pairs_per_substep"] = touching / max((args.steps + args.warmup) * args.substeps, 1)
             result["config"]["manifold_points_per_substep"] = points / max((args.steps + args.warmup) * args.substeps, 1)
