@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational extra measurements (unfused roofline, PCIe-inclusive); for profiling runs")
     ap.add_argument("--joints", type=int, default=0,
                     help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
     ap.add_argument("--pitch", type=float, default=2.0,
@@ -271,7 +273,7 @@ def main():
             result["config"]["neighbour_pairs"] = pairs
             result["config"]["touching_pairs_per_substep"] = touching / max((args.steps + args.warmup) * args.substeps, 1)
             result["config"]["manifold_points_per_substep"] = points / max((args.steps + args.warmup) * args.substeps, 1)
-        if world_size == 1 and mode == capi.MODE_FUSED:
+        if world_size == 1 and mode == capi.MODE_FUSED and not args.no_extras:
             # The same kernel scheduled one launch per substep (state round-trips HBM every substep):
             # the HBM-roofline-comparable form, measured in the same run on the same resident state.
             frames = max(3, min(10, args.steps))
@@ -294,7 +296,7 @@ def main():
                                           "traffic": tr, "kernel": "k_step", "launch_us": sub_s * 1e6,
                                           "body_substeps_per_s": count / sub_s,
                                           "note": "XPBD_MODE_PER_SUBSTEP: one launch per substep, 412 B per body per launch"}
-        if world_size == 1:
+        if world_size == 1 and not args.no_extras:
             # Informational, never `value`: the same frame when the boundary hands over HOST buffers
             # (AoS upload over PCIe -> step -> AoS download), as a literal per-frame drop-in would.
             state = world.download()

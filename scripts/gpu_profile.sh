@@ -7,7 +7,7 @@ TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="python3 bench.py --warmup 40 --no-cpu-baseline"
+B="python3 bench.py --warmup 40 --no-cpu-baseline --no-extras"
 
 timeout -k 10 300 python3 bench.py --steps 60 --warmup 30 > "$OUT/bench_fused.json" 2> "$OUT/bench_fused.err"
 timeout -k 10 300 $B --steps 30 --mode substep > "$OUT/bench_substep.json" 2> "$OUT/bench_substep.err"

@@ -19,7 +19,8 @@ import sys
 
 def rows_of(pattern):
     files = glob.glob(pattern, recursive=True)
-    return list(csv.DictReader(open(files[0]))) if files else []
+    # a directory can hold several runs: take the newest
+    return list(csv.DictReader(open(max(files, key=os.path.getmtime)))) if files else []
 
 
 def pmc(out, name, last):
