@@ -32,8 +32,6 @@ struct Mat3 {
     Vec3 cx, cy, cz;
 };
 
-XPBD_HD Vec3 make_vec3(double x, double y, double z) { return Vec3{x, y, z}; }
-
 XPBD_HD Vec3 operator+(Vec3 a, Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 XPBD_HD Vec3 operator-(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 XPBD_HD Vec3 operator-(Vec3 a) { return Vec3{-a.x, -a.y, -a.z}; }

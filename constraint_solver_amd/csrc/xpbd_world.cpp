@@ -96,7 +96,6 @@ struct xpbd_world {
     // shapes
     DeviceBuffer shape_verts, shape_offsets;
     uint32_t n_shapes = 0, total_verts = 0;
-    std::vector<uint32_t> host_offsets;
 
     // extension: polytope topology for the body-body narrowphase
     DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
@@ -373,7 +372,6 @@ int xpbd_world_set_shapes(xpbd_world *w, const double *verts_xyz, const uint32_t
     XPBD_HIP_TRY(hipMemcpy(w->shape_offsets.ptr, vert_offsets, (size_t)(n_shapes + 1) * 4, hipMemcpyHostToDevice));
     w->n_shapes = n_shapes;
     w->total_verts = total;
-    w->host_offsets.assign(vert_offsets, vert_offsets + n_shapes + 1);
     w->has_topology = false;
     return XPBD_OK;
 }

@@ -336,3 +336,35 @@ def test_sharded_gpu_world_with_joints_equals_single_gpu(tmp_path):
     got = np.load(tmp_path / "sharded.npy")
     bodies, sid = hc.pile(capi, kind, n, seed, width, 6.0)
     assert bits_equal(got, hc.expected(ob, bodies, sid, kind, substeps, frames, pad, hc.chain_joints(capi, n)))
+
+
+def test_full_size_stacks_stand_and_half_worlds_compose():
+    """BASELINE configs[3] size through the contact pipeline: 262 144 stacked boxes.  The oracle is far too slow
+    here, so use properties: columns stay standing, nothing goes NaN, the pair statistics are the expected ones,
+    and (columns being independent) two half-worlds give exactly the whole world's result."""
+    n, frames, substeps = 262144, 4, 20
+    bodies, sid = capi.scene_generate(capi.SCENE_BOX_STACKS, 1, n)
+
+    def run(b, s):
+        with capi.World(mode=capi.MODE_CONTACTS) as w:
+            w.set_polytopes(capi.scene_polytopes(capi.SCENE_BOX_STACKS))
+            w.upload(b, s)
+            for _ in range(frames):
+                w.step(DT, substeps)
+            return w.download(), w.contact_stats()
+
+    whole, stats = run(bodies, sid)
+    assert not np.isnan(whole).any()
+    assert stats[0] == n // 16 * 15                                           # vertical neighbours only
+    assert stats[1] > 0.2 * stats[0] * substeps * frames                      # ... and they do touch once the 1 mm gaps close
+    level = np.arange(n) % 16
+    np.testing.assert_allclose(whole[:, 33], level, atol=0.02)                # every box within 2 cm of its rest height
+    np.testing.assert_allclose(whole[:, 31:33], bodies[:, 31:33], atol=0.02)  # ... and of its column
+    half = n // 2
+    lo, _ = run(bodies[:half], sid[:half])
+    hi, _ = run(bodies[half:], sid[half:])
+    assert bits_equal(np.concatenate([lo, hi]), whole)
+    # columns are the same problem up to a translation, but floating point is not translation invariant
+    # (world-space contact points at x, y up to ~500 m), so they only agree to within the solver's noise
+    z = whole[:, 33].reshape(-1, 16)
+    assert np.abs(z - z[0]).max() < 5e-3
