@@ -309,6 +309,16 @@ def main():
             result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": "body*substeps/s",
                                         "ms_per_frame": per_frame * 1e3,
                                         "what": "pageable host AoS upload + step + download every frame"}
+            # What the reference's app actually needs per frame: state stays resident, only Rigid::frame() of every
+            # body comes back for rendering (src/app.rs:227-232).
+            t0 = time.perf_counter()
+            for _ in range(5):
+                world.step(FRAME_TIME, args.substeps)
+                world.frames()
+            per_frame = (time.perf_counter() - t0) / 5
+            result["render_readback"] = {"value": count * args.substeps / per_frame, "unit": "body*substeps/s",
+                                         "ms_per_frame": per_frame * 1e3,
+                                         "what": "step + download of Rigid::frame() (56 B/body) every frame"}
         if world_size == 1 and not args.no_cpu_baseline and mode != capi.MODE_CONTACTS:
             state = world.download()
             result["cpu_baseline"] = cpu_baseline(state, shape_id, verts, offsets, args.substeps)

@@ -33,7 +33,7 @@ RIGID_FIELDS = {
 ABI_SYMBOLS = [
     "xpbd_abi_version", "xpbd_last_error", "xpbd_config_default", "xpbd_device_count", "xpbd_world_create",
     "xpbd_world_destroy", "xpbd_world_set_shapes", "xpbd_world_upload_bodies", "xpbd_world_download_bodies",
-    "xpbd_world_body_count", "xpbd_world_step", "xpbd_world_synchronize", "xpbd_world_download_contacts",
+    "xpbd_world_body_count", "xpbd_world_download_frames", "xpbd_world_step", "xpbd_world_synchronize", "xpbd_world_download_contacts",
     "xpbd_world_download_contact_masks", "xpbd_world_set_stream", "xpbd_world_get_stream", "xpbd_world_set_mode",
     "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
     "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
@@ -101,6 +101,7 @@ def hip_lib():
         L.xpbd_world_set_shapes.argtypes = [C.c_void_p, _f64p, _u32p, C.c_uint32]
         L.xpbd_world_upload_bodies.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.c_uint32]
         L.xpbd_world_download_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.xpbd_world_download_frames.argtypes = [C.c_void_p, _f64p, C.c_uint32]
         L.xpbd_world_body_count.argtypes = [C.c_void_p]
         L.xpbd_world_body_count.restype = C.c_uint32
         L.xpbd_world_step.argtypes = [C.c_void_p, C.c_double, C.c_uint32]
@@ -211,6 +212,12 @@ class World:
     def download(self):
         out = np.empty((self.n, RIGID_DOUBLES), dtype=np.float64)
         _check(hip_lib().xpbd_world_download_bodies(self._h, out.ctypes.data, self.n))
+        return out
+
+    def frames(self):
+        """(n, 7) Rigid::frame() of every body: origin xyz, rotation sxyz (what the reference's renderer reads)."""
+        out = np.empty((self.n, 7), dtype=np.float64)
+        _check(hip_lib().xpbd_world_download_frames(self._h, _f64(out), self.n))
         return out
 
     def contacts(self):

@@ -67,6 +67,8 @@ hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double
 
 // Frames of all bodies from the SoA state into a [7][stride] array (used by the diagnostic narrowphase).
 hipError_t launch_body_frames(const BodyArrays &b, double *frames, hipStream_t stream);
+// ... and body-major, frames[7 * i + f], for the host read-back.
+hipError_t launch_body_frames_aos(const BodyArrays &b, double *frames, hipStream_t stream);
 
 // Halo exchange: gather / scatter the 13 dynamic fields of the listed bodies, body-major buffer.
 hipError_t launch_export_dynamic(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *buf, hipStream_t stream);

@@ -327,6 +327,24 @@ __global__ void k_body_frames(BodyArrays b, double *__restrict__ frames)
         store_frame(frames, b.stride, i, body_frame(b, i));
 }
 
+// Rigid::frame() of every body, body-major (7 doubles each), staged through LDS so that the global
+// stores are contiguous.
+__global__ void __launch_bounds__(kBlock) k_body_frames_aos(BodyArrays b, double *__restrict__ frames)
+{
+    __shared__ double tile[kBlock * 7];
+    const uint32_t base = blockIdx.x * kBlock, i = base + threadIdx.x;
+    if (i < b.n) {
+        const Frame f = body_frame(b, i);
+        double *t = tile + threadIdx.x * 7;
+        t[0] = f.position.x, t[1] = f.position.y, t[2] = f.position.z;
+        t[3] = f.rotation.s, t[4] = f.rotation.x, t[5] = f.rotation.y, t[6] = f.rotation.z;
+    }
+    __syncthreads();
+    const uint32_t count = min(kBlock, b.n - base);
+    for (uint32_t k = threadIdx.x; k < count * 7; k += kBlock)
+        frames[(size_t)base * 7 + k] = tile[k];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Per substep, per body: Jacobi over the pair contacts, then derive.
 // ---------------------------------------------------------------------------------------------------
@@ -570,6 +588,13 @@ hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double
 {
     if (b.n)
         hipLaunchKernelGGL(k_pair_solve_derive, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_body_frames_aos(const BodyArrays &b, double *frames, hipStream_t stream)
+{
+    if (b.n)
+        hipLaunchKernelGGL(k_body_frames_aos, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, frames);
     return hipGetLastError();
 }
 

@@ -552,6 +552,23 @@ int xpbd_world_download_bodies(xpbd_world *w, xpbd_rigid *aos, uint32_t n)
 
 uint32_t xpbd_world_body_count(const xpbd_world *w) { return w ? w->n : 0; }
 
+int xpbd_world_download_frames(xpbd_world *w, double *frames, uint32_t n)
+{
+    if (!w || (!frames && n))
+        return fail(XPBD_E_INVALID, "xpbd_world_download_frames: NULL argument");
+    if (n != w->n)
+        return fail(XPBD_E_INVALID, "xpbd_world_download_frames: n = %u but the world holds %u bodies", n, w->n);
+    if (n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    // aos_staging holds n * 38 doubles: room for the n * 7 frame doubles
+    XPBD_HIP_TRY(xpbd::launch_body_frames_aos(w->arrays(), w->aos_staging.as<double>(), w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(frames, w->aos_staging.ptr, (size_t)n * 7 * 8, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
 int xpbd_world_step(xpbd_world *w, double dt, uint32_t substeps)
 {
     if (!w)

@@ -54,6 +54,44 @@ pub struct XpbdConfig {
     pub reserved: [u32; 3],
 }
 
+/// EXTENSION (not in the reference): full polytope topology for body-body contacts.
+#[repr(C)]
+pub struct XpbdPolytope {
+    pub vertices_xyz: *const f64,
+    pub edges: *const u32,
+    pub face_offsets: *const u32,
+    pub face_indices: *const u32,
+    pub n_vertices: u32,
+    pub n_edges: u32,
+    pub n_faces: u32,
+    pub reserved: u32,
+    pub centroid: [f64; 3],
+}
+
+/// EXTENSION: contact manifold of one body pair.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct XpbdManifold {
+    pub n_points: u32,
+    pub feature: u32,
+    pub index_a: u32,
+    pub index_b: u32,
+    pub separation: f64,
+    pub p_ref: [[f64; 3]; 8],
+    pub p_inc: [[f64; 3]; 8],
+}
+
+/// EXTENSION: distance / ball joint between two bodies (a hinge is two ball joints on its axis).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct XpbdJoint {
+    pub body_a: u32,
+    pub body_b: u32,
+    pub anchor_a: [f64; 3],
+    pub anchor_b: [f64; 3],
+    pub distance: f64,
+}
+
 #[repr(C)]
 pub struct XpbdWorld {
     _private: [u8; 0],
@@ -80,6 +118,19 @@ extern "C" {
     pub fn xpbd_world_set_mode(w: *mut XpbdWorld, mode: u32) -> c_int;
     pub fn xpbd_step_one(rigid: *mut XpbdRigid, verts_xyz: *const f64, nverts: u32, dt: f64, substeps: u32) -> c_int;
     pub fn xpbd_selftest_div_sqrt(device: i32, a: *const f64, b: *const f64, q: *mut f64, r: *mut f64, n: u32) -> c_int;
+    pub fn xpbd_world_download_frames(w: *mut XpbdWorld, frames: *mut f64, n: u32) -> c_int;
+    // ---- extension: body-body contacts, joints, multi-GPU halo exchange (not in the reference) ----
+    pub fn xpbd_world_set_polytopes(w: *mut XpbdWorld, shapes: *const XpbdPolytope, n_shapes: u32) -> c_int;
+    pub fn xpbd_world_narrowphase(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdManifold) -> c_int;
+    pub fn xpbd_world_set_contact_pad(w: *mut XpbdWorld, pad: f64) -> c_int;
+    pub fn xpbd_world_contact_stats(w: *mut XpbdWorld, out: *mut u64) -> c_int;
+    pub fn xpbd_world_build_neighbours(w: *mut XpbdWorld, dt: f64, n_entries_out: *mut u32) -> c_int;
+    pub fn xpbd_world_download_neighbours(w: *mut XpbdWorld, offsets: *mut u32, neighbours: *mut u32, cap: u32) -> c_int;
+    pub fn xpbd_world_set_joints(w: *mut XpbdWorld, joints: *const XpbdJoint, n_joints: u32) -> c_int;
+    pub fn xpbd_world_contacts_begin(w: *mut XpbdWorld, dt: f64) -> c_int;
+    pub fn xpbd_world_contacts_substep(w: *mut XpbdWorld, h: f64) -> c_int;
+    pub fn xpbd_world_export_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *mut f64) -> c_int;
+    pub fn xpbd_world_import_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *const f64) -> c_int;
 }
 
 fn v3(v: Vector3<f64>) -> [f64; 3] {

@@ -117,6 +117,9 @@ int  xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos,
                               const uint32_t *shape_id, uint32_t n);
 int  xpbd_world_download_bodies(xpbd_world *w, xpbd_rigid *aos, uint32_t n);
 uint32_t xpbd_world_body_count(const xpbd_world *w);
+/* Rigid::frame() of every body (src/rigid.rs:75-80), the only thing the reference's renderer reads per
+ * frame (src/app.rs:227-230): frames[7*i .. 7*i+6] = origin x y z, rotation s x y z.  56 B/body instead of 304. */
+int  xpbd_world_download_frames(xpbd_world *w, double *frames, uint32_t n);
 
 /* for each body: solver::step(body, shape[body], dt, substeps).  Asynchronous. */
 int  xpbd_world_step(xpbd_world *w, double dt, uint32_t substeps);

@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.xpbd_abi_version() == 1
 
 
+def test_rust_binding_text_declares_every_symbol():
+    """constraint_solver_amd/ffi/xpbd_ffi.rs cannot be compiled here (no rustc); at least keep it complete."""
+    text = open(os.path.join(ROOT, "constraint_solver_amd", "ffi", "xpbd_ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (xpbd_[a-z_0-9]+)\(", text))
+    assert declared == set(header_functions())
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.Config) == 32
     assert capi.RIGID_DOUBLES * 8 == 304

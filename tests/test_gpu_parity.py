@@ -115,6 +115,18 @@ def test_step_one_is_solver_step(oracle):
         assert bits_equal(capi.step_one(b, verts, DT, 25), r.np())
 
 
+def test_frame_readback_is_rigid_frame():
+    bodies, sid = capi.scene_generate(capi.SCENE_MIXED, 3, 1000)
+    verts, off = capi.scene_shapes(capi.SCENE_MIXED)
+    with capi.World() as w:
+        w.set_shapes(verts, off)
+        w.upload(bodies, sid)
+        w.step(DT, 20)
+        state, frames = w.download(), w.frames()
+    want = np.array([capi.rigid_frame(b) for b in state])        # host mirror's Rigid::frame(), bit-exact vs the oracle
+    assert bits_equal(frames, want)
+
+
 # ---------------------------------------------------------------- edge cases
 def test_empty_world_and_single_body():
     verts, off = capi.scene_shapes(capi.SCENE_BOXES)
