@@ -17,6 +17,7 @@
 #include "xpbd_kernels.h"
 #include "xpbd_math.hpp"
 #include "xpbd_contacts.h"
+#include "xpbd_gjk.h"
 #include "xpbd_pairs.h"
 
 namespace {
@@ -712,6 +713,36 @@ int xpbd_step_one(xpbd_rigid *rigid, const double *verts_xyz, uint32_t nverts, d
     if (int rc = xpbd_world_step(cache.w, dt, substeps))
         return rc;
     return xpbd_world_download_bodies(cache.w, rigid, 1);
+}
+
+int xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_gjk_result *out)
+{
+    static_assert(sizeof(xpbd_gjk_result) == sizeof(xpbd::GjkResult), "xpbd_gjk_result must mirror xpbd::GjkResult");
+    if (!w || (n_pairs && (!pairs || !out)))
+        return fail(XPBD_E_INVALID, "xpbd_world_narrowphase_gjk: NULL argument");
+    if (!w->has_topology)
+        return fail(XPBD_E_INVALID, "xpbd_world_narrowphase_gjk: call xpbd_world_set_polytopes first");
+    for (uint32_t k = 0; k < 2 * n_pairs; ++k)
+        if (pairs[k] >= w->n)
+            return fail(XPBD_E_INVALID, "xpbd_world_narrowphase_gjk: pair %u names body %u of %u", k / 2, pairs[k], w->n);
+    if (n_pairs == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    XPBD_HIP_TRY(w->pair_buf.reserve((size_t)n_pairs * 8));
+    XPBD_HIP_TRY(w->manifold_buf.reserve((size_t)n_pairs * sizeof(xpbd::GjkResult)));
+    XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * w->stride * 8));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemsetAsync(w->manifold_buf.ptr, 0, (size_t)n_pairs * sizeof(xpbd::GjkResult), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(),
+                                            w->pair_buf.as<uint32_t>(), n_pairs, w->manifold_buf.as<xpbd::GjkResult>(),
+                                            w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::GjkResult), hipMemcpyDeviceToHost,
+                                w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
 }
 
 int xpbd_world_set_joints(xpbd_world *w, const xpbd_joint *joints, uint32_t n_joints)

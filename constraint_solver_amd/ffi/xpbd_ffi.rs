@@ -92,6 +92,20 @@ pub struct XpbdJoint {
     pub distance: f64,
 }
 
+/// EXTENSION: result of the GJK + EPA narrowphase for one pair.
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct XpbdGjkResult {
+    pub status: i32,
+    pub gjk_iterations: u32,
+    pub epa_iterations: u32,
+    pub reserved: u32,
+    pub depth: f64,
+    pub normal: [f64; 3],
+    pub point_a: [f64; 3],
+    pub point_b: [f64; 3],
+}
+
 #[repr(C)]
 pub struct XpbdWorld {
     _private: [u8; 0],
@@ -122,6 +136,7 @@ extern "C" {
     // ---- extension: body-body contacts, joints, multi-GPU halo exchange (not in the reference) ----
     pub fn xpbd_world_set_polytopes(w: *mut XpbdWorld, shapes: *const XpbdPolytope, n_shapes: u32) -> c_int;
     pub fn xpbd_world_narrowphase(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdManifold) -> c_int;
+    pub fn xpbd_world_narrowphase_gjk(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdGjkResult) -> c_int;
     pub fn xpbd_world_set_contact_pad(w: *mut XpbdWorld, pad: f64) -> c_int;
     pub fn xpbd_world_contact_stats(w: *mut XpbdWorld, out: *mut u64) -> c_int;
     pub fn xpbd_world_build_neighbours(w: *mut XpbdWorld, dt: f64, n_entries_out: *mut u32) -> c_int;

@@ -193,6 +193,22 @@ int  xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32
 int  xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs,
                             xpbd_manifold *out);
 
+/* GJK + EPA narrowphase of the given pairs (the reference has neither): boolean GJK on the
+ * Minkowski difference built with the reference's support convention (src/geometry.rs:274-289), then EPA for the
+ * penetration depth, the normal (from A to B) and one witness point on each body.  One wave per pair. */
+#define XPBD_GJK_SEPARATED   0
+#define XPBD_GJK_PENETRATING 1
+#define XPBD_GJK_DEGENERATE  2  /* origin on the simplex boundary / flat simplex / iteration cap: use the SAT */
+typedef struct xpbd_gjk_result {
+    int32_t  status;
+    uint32_t gjk_iterations, epa_iterations, reserved;
+    double   depth;
+    double   normal[3];
+    double   point_a[3];
+    double   point_b[3];   /* point_a - point_b = depth * normal */
+} xpbd_gjk_result;
+int  xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_gjk_result *out);
+
 /* XPBD_MODE_CONTACTS: per xpbd_world_step a sphere broadphase builds sorted neighbour lists
  * (sphere = centroid, r_shape + min(|v| dt, r_shape) + pad); per substep: integrate -> SAT of every neighbour
  * pair -> ground contacts (reference path) -> pair contacts, Jacobi-averaged with a fixed

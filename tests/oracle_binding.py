@@ -296,3 +296,22 @@ def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad):
         L.op_contacts_substep(f, b.ctypes.data, dt / substeps, None, None)
     L.op_contacts_end(f)
     return b
+
+
+# ---- GJK + EPA (oracle/xpbd_gjk_oracle.c; extension, parity unpinned) ---------------------------
+class GjkResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("gjk_iterations", C.c_uint32), ("epa_iterations", C.c_uint32),
+                ("reserved", C.c_uint32), ("depth", C.c_double), ("normal", Vec3), ("point_a", Vec3), ("point_b", Vec3)]
+
+
+GJK_SEPARATED, GJK_PENETRATING, GJK_DEGENERATE = 0, 1, 2
+
+
+def gjk_epa(fa, fb, pa, pb):
+    L = load()
+    if not hasattr(L, "_gjk_ready"):
+        L.og_gjk_epa.restype, L.og_gjk_epa.argtypes = None, [Frame, Frame, C.POINTER(Polytope), C.POINTER(Polytope), C.POINTER(GjkResult)]
+        L._gjk_ready = True
+    r = GjkResult()
+    L.og_gjk_epa(frame(*fa), frame(*fb), C.byref(pa), C.byref(pb), C.byref(r))
+    return r

@@ -368,3 +368,38 @@ def test_full_size_stacks_stand_and_half_worlds_compose():
     # (world-space contact points at x, y up to ~500 m), so they only agree to within the solver's noise
     z = whole[:, 33].reshape(-1, 16)
     assert np.abs(z - z[0]).max() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# GJK + EPA narrowphase (extension)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,n,spread", [(capi.SCENE_BOXES, 160, 1.6), (capi.SCENE_MIXED, 150, 1.0)])
+def test_gjk_epa_kernel_matches_oracle(kind, n, spread):
+    bodies, sid = cluster(kind, n, 33, spread)
+    rng = np.random.default_rng(4)
+    pairs = rng.integers(0, n, (4000, 2)).astype(np.uint32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    with capi.World() as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.upload(bodies, sid)
+        got = w.narrowphase_gjk(pairs)
+        sat = w.narrowphase(pairs)
+    L = ob.load()
+    polys = {k: ob.polytope(*v) for k, v in ORACLE_POLYS.items()}
+    frames = []
+    for b in bodies:
+        f = L.o_rigid_frame(C.byref(ob.Rigid.from_np(b)))
+        frames.append((f.position.np(), f.rotation.np()))
+    n_pen = 0
+    for g, (i, j), m in zip(got, pairs, sat):
+        r = ob.gjk_epa(frames[i], frames[j], polys[int(sid[i])], polys[int(sid[j])])
+        assert (g["status"], g["gjk_iterations"], g["epa_iterations"]) == (r.status, r.gjk_iterations, r.epa_iterations)
+        if r.status == ob.GJK_PENETRATING:
+            n_pen += 1
+            assert bits_equal(np.array([g["depth"]]), np.array([r.depth]))
+            assert bits_equal(g["normal"], r.normal.np()) and bits_equal(g["point_a"], r.point_a.np())
+            assert bits_equal(g["point_b"], r.point_b.np())
+            # and the two narrowphases of the GPU agree with each other: EPA depth == SAT depth
+            assert m["n_points"] == 0 or abs(g["depth"] + m["separation"]) < 2e-6   # SAT's face-preference bias is 1 um
+        assert (r.status == ob.GJK_PENETRATING) == (m["n_points"] > 0) or r.status == ob.GJK_DEGENERATE or m["n_points"] == 0
+    assert 0.1 * len(pairs) < n_pen < 0.9 * len(pairs)
