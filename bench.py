@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the informational extra measurements (unfused roofline, PCIe-inclusive); for profiling runs")
+    ap.add_argument("--narrowphase", default="sat", choices=["sat", "gjk"],
+                    help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (one point per pair)")
     ap.add_argument("--joints", type=int, default=0,
                     help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
     ap.add_argument("--pitch", type=float, default=2.0,
@@ -195,6 +197,7 @@ def main():
     world = capi.World(device=local_rank, mode=mode, block_size=args.block_size)
     if mode == capi.MODE_CONTACTS:
         world.set_polytopes(capi.scene_polytopes(kind))
+        world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if args.narrowphase == "gjk" else capi.NARROWPHASE_SAT)
     else:
         world.set_shapes(verts, offsets)
     world.upload(bodies, shape_id)                       # inputs resident in HBM before any timing
@@ -270,6 +273,7 @@ def main():
             result["config"]["extension"] = ("body-body contacts: NOT in the reference (parity unpinned); roofline "
                                              "fields price only the per-body state traffic")
             result["config"]["joints"] = args.joints
+            result["config"]["narrowphase"] = args.narrowphase
             result["config"]["neighbour_pairs"] = pairs
             result["config"]["touching_pairs_per_substep"] = touching / max((args.steps + args.warmup) * args.substeps, 1)
             result["config"]["manifold_points_per_substep"] = points / max((args.steps + args.warmup) * args.substeps, 1)

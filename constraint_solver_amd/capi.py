@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
     "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_set_joints",
-    "xpbd_world_narrowphase_gjk",
+    "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
 ]
 
 
@@ -72,6 +72,7 @@ JOINT_DTYPE = np.dtype([("body_a", "<u4"), ("body_b", "<u4"), ("anchor_a", "<f8"
 GJK_DTYPE = np.dtype([("status", "<i4"), ("gjk_iterations", "<u4"), ("epa_iterations", "<u4"), ("reserved", "<u4"),
                       ("depth", "<f8"), ("normal", "<f8", (3,)), ("point_a", "<f8", (3,)), ("point_b", "<f8", (3,))])
 GJK_SEPARATED, GJK_PENETRATING, GJK_DEGENERATE = 0, 1, 2
+NARROWPHASE_SAT, NARROWPHASE_GJK_EPA = 0, 1
 MAX_MANIFOLD_POINTS = 8
 FEATURE_FACE_A, FEATURE_FACE_B, FEATURE_EDGES = 0, 1, 2
 # xpbd_manifold as a numpy record (408 bytes)
@@ -122,6 +123,7 @@ def hip_lib():
         L.xpbd_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
         L.xpbd_world_narrowphase.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         L.xpbd_world_narrowphase_gjk.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_set_narrowphase.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_world_set_contact_pad.argtypes = [C.c_void_p, C.c_double]
         L.xpbd_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.xpbd_world_build_neighbours.argtypes = [C.c_void_p, C.c_double, _u32p]
@@ -269,6 +271,9 @@ class World:
         out = np.zeros(pr.shape[0], dtype=GJK_DTYPE)
         _check(hip_lib().xpbd_world_narrowphase_gjk(self._h, _u32(pr), pr.shape[0], out.ctypes.data))
         return out
+
+    def set_narrowphase(self, narrowphase):
+        _check(hip_lib().xpbd_world_set_narrowphase(self._h, narrowphase))
 
     def set_contact_pad(self, pad):
         _check(hip_lib().xpbd_world_set_contact_pad(self._h, pad))

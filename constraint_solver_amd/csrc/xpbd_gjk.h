@@ -20,8 +20,9 @@ struct GjkResult {
     double point_a[3], point_b[3];
 };
 
-// One wave per pair, as launch_sat_pairs.
+// One wave per pair, as launch_sat_pairs.  `out` and `manifolds` may each be NULL: manifolds receives the result as
+// a one-point Manifold (reference body A, incident body B) for the contact pipeline.
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                                uint32_t n_pairs, GjkResult *out, hipStream_t stream);
+                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, hipStream_t stream);
 
 } // namespace xpbd

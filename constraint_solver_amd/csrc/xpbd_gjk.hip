@@ -180,9 +180,11 @@ __device__ __forceinline__ uint32_t closest_face(const GjkLds &s, uint32_t nf, u
     return bi;
 }
 
+// out: per-pair GjkResult (diagnostic entry point) and/or manifolds: one-point Manifold for the contact pipeline
+// (A = reference body, B = incident body; a degenerate query yields no contact).
 __global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                       const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                      GjkResult *__restrict__ out)
+                                                      GjkResult *__restrict__ out, Manifold *__restrict__ manifolds)
 {
     __shared__ GjkLds s;
     const uint32_t p = blockIdx.x, lane = threadIdx.x;
@@ -192,15 +194,20 @@ __global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTabl
     const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
     const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
     const ShapeDesc da = t.desc[sa], db = t.desc[sb];
-    GjkResult *r = out + p;
+    GjkResult *r = out ? out + p : nullptr;
+    Manifold *mf = manifolds ? manifolds + p : nullptr;
 
     int32_t status = 0; // separated
     uint32_t gjk_iters = 0, epa_iters = 0;
     auto finish = [&](int32_t st) {
         if (lane == 0) {
-            r->status = st;
-            r->gjk_iterations = gjk_iters;
-            r->epa_iterations = epa_iters;
+            if (r) {
+                r->status = st;
+                r->gjk_iterations = gjk_iters;
+                r->epa_iterations = epa_iters;
+            }
+            if (mf && st != 1)
+                mf->n_points = 0;
         }
     };
     if (da.n_verts == 0 || db.n_verts == 0) {
@@ -404,10 +411,20 @@ __global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTabl
         const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
         const Vec3 pa = ld3(s.va, i0) * bu + ld3(s.va, i1) * bv + ld3(s.va, i2) * bw;
         const Vec3 pb = ld3(s.vb, i0) * bu + ld3(s.vb, i1) * bv + ld3(s.vb, i2) * bw;
-        r->depth = best_dist;
-        r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
-        r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
-        r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
+        if (r) {
+            r->depth = best_dist;
+            r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
+            r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
+            r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
+        }
+        if (mf) {
+            mf->n_points = 1;
+            mf->feature = 2; // reference body A, incident body B
+            mf->index_a = mf->index_b = 0;
+            mf->separation = -best_dist;
+            mf->p_ref[0][0] = pa.x, mf->p_ref[0][1] = pa.y, mf->p_ref[0][2] = pa.z;
+            mf->p_inc[0][0] = pb.x, mf->p_inc[0][1] = pb.y, mf->p_inc[0][2] = pb.z;
+        }
     }
     (void)status;
     finish(1);
@@ -416,10 +433,11 @@ __global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTabl
 } // namespace
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                                uint32_t n_pairs, GjkResult *out, hipStream_t stream)
+                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, hipStream_t stream)
 {
     if (n_pairs)
-        hipLaunchKernelGGL(k_gjk_epa_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        hipLaunchKernelGGL(k_gjk_epa_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
+                           manifolds);
     return hipGetLastError();
 }
 

@@ -50,6 +50,9 @@ struct Manifold {
 
 // One wave per pair: pairs[2*p], pairs[2*p+1] are body indices (A, B).  frames: [7][stride] object->world
 // frames of all bodies (origin xyz, rotation s x y z).  stats (optional): [0] += touching pairs, [1] += points.
+// Block-reduced statistics of a manifold array: stats[0] += touching pairs, stats[1] += contact points.
+hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream);
+
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                             uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream);
 

@@ -379,6 +379,13 @@ __global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pair
 
 } // namespace
 
+hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream)
+{
+    if (n_pairs && stats)
+        hipLaunchKernelGGL(k_manifold_stats, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, m, n_pairs, stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                             uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream)
 {

@@ -111,6 +111,7 @@ struct xpbd_world {
 
     // extension: contact pipeline (XPBD_MODE_CONTACTS)
     double contact_pad = 0.02;
+    uint32_t narrowphase = XPBD_NARROWPHASE_SAT;
     DeviceBuffer dyn_alt, cb_centers, cb_radius, cb_cell, cb_key, cb_maxr, cb_bucket_start, cb_bucket_cursor, cb_items,
         cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_frame_p1, cb_frame_past,
         cb_past_pos, cb_manifolds, cb_stats, cb_scan;
@@ -228,7 +229,12 @@ int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_ro
     const xpbd::BodyArrays b = w->arrays();
     const xpbd::ContactBuffers c = w->contact_buffers();
     XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, trace_row, w->stream));
-    XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
+    if (w->narrowphase == XPBD_NARROWPHASE_GJK_EPA) {
+        XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds, w->stream));
+        XPBD_HIP_TRY(xpbd::launch_manifold_stats(c.manifolds, w->n_pairs, c.stats, w->stream));
+    } else {
+        XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
+    }
     XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
     std::swap(w->dyn, w->dyn_alt);
     return XPBD_OK;
@@ -738,7 +744,7 @@ int xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_
     XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
     XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(),
                                             w->pair_buf.as<uint32_t>(), n_pairs, w->manifold_buf.as<xpbd::GjkResult>(),
-                                            w->stream));
+                                            nullptr, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::GjkResult), hipMemcpyDeviceToHost,
                                 w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
@@ -826,6 +832,14 @@ int xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32
     if (int rc = bind_device(w))
         return rc;
     XPBD_HIP_TRY(xpbd::launch_import_dynamic(w->arrays(), dev_indices, n, dev_buf, w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_set_narrowphase(xpbd_world *w, uint32_t narrowphase)
+{
+    if (!w || (narrowphase != XPBD_NARROWPHASE_SAT && narrowphase != XPBD_NARROWPHASE_GJK_EPA))
+        return fail(XPBD_E_INVALID, "xpbd_world_set_narrowphase: bad argument");
+    w->narrowphase = narrowphase;
     return XPBD_OK;
 }
 

@@ -208,6 +208,11 @@ typedef struct xpbd_gjk_result {
     double   point_b[3];   /* point_a - point_b = depth * normal */
 } xpbd_gjk_result;
 int  xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_gjk_result *out);
+/* Narrowphase used by XPBD_MODE_CONTACTS: the SAT (default: up to 8 points per pair) or GJK + EPA (one point
+ * per pair, reference body A / incident body B; a degenerate query gives no contact in that substep). */
+#define XPBD_NARROWPHASE_SAT     0u
+#define XPBD_NARROWPHASE_GJK_EPA 1u
+int  xpbd_world_set_narrowphase(xpbd_world *w, uint32_t narrowphase);
 
 /* XPBD_MODE_CONTACTS: per xpbd_world_step a sphere broadphase builds sorted neighbour lists
  * (sphere = centroid, r_shape + min(|v| dt, r_shape) + pad); per substep: integrate -> SAT of every neighbour

@@ -3,6 +3,7 @@
  * Test infrastructure only; PARITY UNPINNED (see xpbd_pairs_oracle.h).
  */
 #include "xpbd_pairs_oracle.h"
+#include "xpbd_gjk_oracle.h"
 
 #include <float.h>
 #include <math.h>
@@ -332,7 +333,26 @@ struct op_frame {
     o_rigid *next;
     const op_joint *joints;
     uint32_t n_joints;
+    int narrowphase; /* OP_NARROWPHASE_* */
 };
+
+void op_contacts_set_narrowphase(op_frame *f, int narrowphase) { f->narrowphase = narrowphase; }
+
+/* GJK + EPA result as a one-point manifold: A is the reference body, B the incident one. */
+static void gjk_manifold(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, op_manifold *m)
+{
+    og_result r;
+    og_gjk_epa(fa, fb, pa, pb, &r);
+    memset(m, 0, sizeof *m);
+    m->separated = r.status != OG_PENETRATING; /* a degenerate query yields no contact in this substep */
+    if (m->separated)
+        return;
+    m->feature = OP_FEATURE_EDGES;
+    m->separation = -r.depth;
+    m->n_points = 1;
+    m->p_ref[0] = r.point_a;
+    m->p_inc[0] = r.point_b;
+}
 
 void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_joints)
 {
@@ -434,8 +454,12 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
                 uint32_t j = nb[k];
                 if (j <= i)
                     continue;
-                op_sat(p1[i], p1[j], &shapes[shape_id ? shape_id[i] : 0], &shapes[shape_id ? shape_id[j] : 0],
-                       &manifolds[q]);
+                if (f->narrowphase == OP_NARROWPHASE_GJK_EPA)
+                    gjk_manifold(p1[i], p1[j], &shapes[shape_id ? shape_id[i] : 0], &shapes[shape_id ? shape_id[j] : 0],
+                                 &manifolds[q]);
+                else
+                    op_sat(p1[i], p1[j], &shapes[shape_id ? shape_id[i] : 0], &shapes[shape_id ? shape_id[j] : 0],
+                           &manifolds[q]);
                 if (manifolds[q].separated)
                     manifolds[q].n_points = 0;
                 if (stats && manifolds[q].n_points) {

@@ -110,6 +110,12 @@ typedef struct {
 /* Must be called between begin and the first substep; `joints` must outlive the frame. */
 void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_joints);
 
+/* Narrowphase of step 2: the SAT above (default) or GJK + EPA (xpbd_gjk_oracle.h), which yields ONE contact
+ * point per touching pair (reference body A, incident body B; a degenerate query yields no contact). */
+#define OP_NARROWPHASE_SAT     0
+#define OP_NARROWPHASE_GJK_EPA 1
+void op_contacts_set_narrowphase(op_frame *f, int narrowphase);
+
 void op_contacts_step(o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                       double dt, uint32_t substeps, double pad, uint32_t *ground_masks, op_contact_stats *stats);
 

@@ -282,8 +282,8 @@ def _frames_api():
     return L
 
 
-def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad):
-    """One frame of op_contacts_* with joints (numpy records with the layout of `Joint`)."""
+def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, narrowphase=0):
+    """One frame of op_contacts_* with joints (numpy records with the layout of `Joint`); narrowphase 1 = GJK + EPA."""
     L = _frames_api()
     b = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
     n = b.shape[0]
@@ -292,6 +292,8 @@ def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad):
     assert j.dtype.itemsize == C.sizeof(Joint)
     f = L.op_contacts_begin(b.ctypes.data, sid.ctypes.data_as(C.POINTER(C.c_uint32)), n, polys, dt, pad)
     L.op_contacts_attach_joints(f, j.ctypes.data if j.size else None, j.size)
+    L.op_contacts_set_narrowphase.restype, L.op_contacts_set_narrowphase.argtypes = None, [C.c_void_p, C.c_int]
+    L.op_contacts_set_narrowphase(f, narrowphase)
     for _ in range(substeps):
         L.op_contacts_substep(f, b.ctypes.data, dt / substeps, None, None)
     L.op_contacts_end(f)

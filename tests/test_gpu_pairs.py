@@ -403,3 +403,31 @@ def test_gjk_epa_kernel_matches_oracle(kind, n, spread):
             assert m["n_points"] == 0 or abs(g["depth"] + m["separation"]) < 2e-6   # SAT's face-preference bias is 1 um
         assert (r.status == ob.GJK_PENETRATING) == (m["n_points"] > 0) or r.status == ob.GJK_DEGENERATE or m["n_points"] == 0
     assert 0.1 * len(pairs) < n_pen < 0.9 * len(pairs)
+
+
+def test_contact_pipeline_with_gjk_epa_narrowphase_matches_oracle():
+    """BASELINE configs[2] path in miniature: mixed polyhedra colliding, narrowphase = GJK + EPA (one contact per pair)."""
+    kind, n = capi.SCENE_MIXED_DROP, 180
+    bodies, sid = pile(kind, n, 12, 2.5, 6.0)
+    polys = ob.polytopes_array(POLY_NAMES[kind])
+    none = np.zeros(0, dtype=capi.JOINT_DTYPE)
+    want = bodies
+    for _ in range(30):
+        want = ob.contacts_step_joints(want, sid, polys, none, DT, 10, 0.02, narrowphase=1)
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.set_narrowphase(capi.NARROWPHASE_GJK_EPA)
+        w.upload(bodies, sid)
+        for _ in range(30):
+            w.step(DT, 10)
+        stats = w.contact_stats()
+        got = w.download()
+        assert bits_equal(got, want)
+        assert stats[1] > 50 and stats[2] == stats[1]                 # touching pairs, exactly one point each
+        with pytest.raises(capi.XpbdError):
+            w.set_narrowphase(7)
+    # the SAT path gives a different (multi-point) answer on the same scene
+    sat_want = bodies
+    for _ in range(30):
+        sat_want, _, _ = ob.contacts_step(sat_want, sid, polys, DT, 10, 0.02)
+    assert not bits_equal(sat_want, want)
