@@ -17,8 +17,8 @@ namespace xpbd {
 struct ShapeDesc {
     uint32_t vert0, n_verts;   // into verts (shared with ShapeTable::verts)
     uint32_t face0, n_faces;   // into planes / face_start
-    uint32_t edge0, n_edges;   // into edges
-    uint32_t pad0, pad1;
+    uint32_t edge0, n_edges;   // into edges / edge_dir_id
+    uint32_t dir0, n_dirs;     // into edge_dirs: unique edge directions (up to sign)
 };
 
 struct PolytopeTables {
@@ -30,13 +30,14 @@ struct PolytopeTables {
     const uint32_t *face_verts;  // shape-local vertex indices of every face, back to back
     const uint32_t *edges;       // [total_edges][2] shape-local vertex indices
     const double *radii;         // [n_shapes] max |vertex - centroid|
+    const double *edge_dirs;     // [total_dirs][3] shape-local direction v[e.1] - v[e.0] of the first edge with it
+    const uint32_t *edge_dir_id; // [total_edges] shape-local index of every edge's direction
     uint32_t n_shapes;
 };
 
 constexpr uint32_t kMaxManifoldPoints = 8;
 constexpr uint32_t kMaxFaceVerts = 8;      // vertices per face accepted by the clipper
 constexpr double kEdgeBias = 1e-6;         // an edge axis must beat both face axes by this much (metres)
-constexpr double kSupportTol = 1e-9;       // slack of the "edge is a supporting feature" tests (metres)
 
 // Result of one pair, 16-byte header + 8 x 2 points (xpbd_manifold in include/xpbd.h has this layout).
 struct Manifold {

@@ -5,15 +5,15 @@
 // exists); the checker is oracle/xpbd_pairs_oracle.c.  Conventions kept from the reference:
 //   face_axes_separation  src/collision.rs:123-149  support = LAST maximum under f64::total_cmp,
 //                                                   face   = FIRST maximum ('>')
-//   edge_axes_separation  src/collision.rs:151-197  axis = normalize(eA x eB) flipped away from A's
-//                                                   centroid; pair skipped if A reaches past the foot;
-//                                                   parallel edges give a NaN axis and contribute nothing
+//   edge_axes_separation  src/collision.rs:151-197  parallel edges give a NaN axis and contribute nothing,
+//                                                   first maximum; its E_A x E_B pair enumeration is replaced
+//                                                   by the classic test over UNIQUE edge directions
 //   feature choice        src/collision.rs:47-59,89-92 (comments there)
 //   reference plane / incident face  src/collision.rs:66, 76-85 (first minimum of n . n_ref)
 //
 // Mapping: ONE WAVE = ONE CANDIDATE PAIR.  Both bodies' vertices are transformed once into LDS
 // (world space, and each into the other's local space); lanes then run in parallel over
-// faces x vertices, over the E_A x E_B edge pairs and over the incident body's faces, and combine
+// faces x vertices, over the pairs of unique edge directions and over the incident body's faces, and combine
 // with __shfl_xor reductions that carry (value, index) so the reference's first/last tie-breaks
 // survive the parallel order.  Clipping runs one polygon vertex per lane with wave prefix sums.
 #include <cfloat>
@@ -159,51 +159,42 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
         return;
     }
 
-    // ---- edge query (src/collision.rs:151-197): E_A x E_B pairs strided over the 64 lanes ---------
+    // ---- edge axes: (unique edge direction of A) x (unique edge direction of B), strided over the lanes ----
+    // n = normalize(dA x dB) pointing from A's centroid to B's; separation = min_B n.b - max_A n.a.
+    // Parallel directions give a NaN axis and contribute nothing; first maximum wins (ascending pair index).
     double ebest = -DBL_MAX;
     uint32_t eq = kNone;
+    const double *cca = t.centroids + 3 * (size_t)sa, *ccb = t.centroids + 3 * (size_t)sb;
+    const Vec3 a_to_b = fb * Vec3{ccb[0], ccb[1], ccb[2]} - fa * Vec3{cca[0], cca[1], cca[2]};
+    auto edge_axis = [&](uint32_t i, uint32_t j, Vec3 &axis) -> bool {
+        const double *da_ = t.edge_dirs + 3 * (size_t)(da.dir0 + i), *db_ = t.edge_dirs + 3 * (size_t)(db.dir0 + j);
+        Vec3 n = normalized(cross(fa.rotation * Vec3{da_[0], da_[1], da_[2]}, fb.rotation * Vec3{db_[0], db_[1], db_[2]}));
+        if (!finite3(n))
+            return false;
+        if (dot(n, a_to_b) < 0.0)
+            n = -n;
+        axis = n;
+        return true;
+    };
     {
-        const double *cc = t.centroids + 3 * (size_t)sa;
-        const Vec3 centroid_a = fa * Vec3{cc[0], cc[1], cc[2]};
-        const uint32_t total = da.n_edges * db.n_edges;
+        const uint32_t total = da.n_dirs * db.n_dirs;
         for (uint32_t q = lane; q < total; q += 64) {
-            const uint32_t i = q / db.n_edges, j = q - i * db.n_edges;
-            const uint32_t *ea = t.edges + 2 * (size_t)(da.edge0 + i), *eb = t.edges + 2 * (size_t)(db.edge0 + j);
-            const Vec3 foot = ld3(s.world[0], ea[0]);
-            const Vec3 e0 = ld3(s.world[0], ea[1]) - foot;
-            const Vec3 b0 = ld3(s.world[1], eb[0]);
-            const Vec3 e1 = ld3(s.world[1], eb[1]) - b0;
-            Vec3 axis = normalized(cross(e0, e1));
-            if (!finite3(axis))
-                continue; // parallel (NaN) or degenerate axis: every comparison below is false in the reference too
-            if (dot(axis, foot - centroid_a) < 0.0)
-                axis = -axis;
-            // "Ignore if another point on `a` is further in the direction to `b`" -- with a tolerance
-            // (the edge's own second endpoint beats the foot by rounding noise otherwise) ...
-            double reach = dot(ld3(s.world[0], 0), axis);
+            const uint32_t i = q / db.n_dirs, j = q - i * db.n_dirs;
+            Vec3 axis;
+            if (!edge_axis(i, j, axis))
+                continue;
+            double reach_a = dot(ld3(s.world[0], 0), axis), reach_b = dot(ld3(s.world[1], 0), axis);
             for (uint32_t v = 1; v < da.n_verts; ++v) {
-                const double r = dot(ld3(s.world[0], v), axis);
-                if (r > reach)
-                    reach = r;
+                const double rr = dot(ld3(s.world[0], v), axis);
+                if (rr > reach_a)
+                    reach_a = rr;
             }
-            if (reach > dot(foot, axis) + kSupportTol)
-                continue;
-            // ... and mirrored for B, so that both edges are supporting features (extension rule).
-            const Vec3 nax = -axis;
-            Vec3 sup = ld3(s.world[1], 0);
-            double breach = dot(sup, nax);
             for (uint32_t v = 1; v < db.n_verts; ++v) {
-                const Vec3 x = ld3(s.world[1], v);
-                const double r = dot(x, nax);
-                if (r >= breach) { // last maximum, as Polytope::support
-                    breach = r;
-                    sup = x;
-                }
+                const double rr = dot(ld3(s.world[1], v), axis);
+                if (rr < reach_b)
+                    reach_b = rr;
             }
-            if (breach > dot(b0, nax) + kSupportTol)
-                continue;
-            const Plane pl = plane_from_point_normal(foot, axis);
-            const double dist = distance(pl, sup);
+            const double dist = reach_b - reach_a;
             if (dist > ebest) { // ascending q on this lane: first maximum
                 ebest = dist;
                 eq = q;
@@ -222,8 +213,41 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     const bool use_edges = eq != kNone && ebest > face_best + kEdgeBias;
 
     if (use_edges) {
+        // supporting edges of the winning axis: A's edge of that direction furthest along the axis, B's edge
+        // furthest against it (sum of the endpoint projections, first extremum); one edge per lane
+        const uint32_t di = eq / db.n_dirs, dj = eq - di * db.n_dirs;
+        Vec3 axis;
+        (void)edge_axis(di, dj, axis);
+        double sa_best = -DBL_MAX, sb_best = DBL_MAX;
+        uint32_t edge_i = kNone, edge_j = kNone;
+        for (uint32_t e = lane; e < da.n_edges; e += 64) {
+            if (t.edge_dir_id[da.edge0 + e] != di)
+                continue;
+            const uint32_t *ev = t.edges + 2 * (size_t)(da.edge0 + e);
+            const double sp = dot(ld3(s.world[0], ev[0]), axis) + dot(ld3(s.world[0], ev[1]), axis);
+            if (sp > sa_best) {
+                sa_best = sp;
+                edge_i = e;
+            }
+        }
+        for (uint32_t e = lane; e < db.n_edges; e += 64) {
+            if (t.edge_dir_id[db.edge0 + e] != dj)
+                continue;
+            const uint32_t *ev = t.edges + 2 * (size_t)(db.edge0 + e);
+            const double sp = dot(ld3(s.world[1], ev[0]), axis) + dot(ld3(s.world[1], ev[1]), axis);
+            if (sp < sb_best) {
+                sb_best = sp;
+                edge_j = e;
+            }
+        }
+        reduce_max_first(sa_best, edge_i, 64);
+        reduce_min_first(sb_best, edge_j, 64);
+        if (edge_i == kNone)
+            edge_i = 0;
+        if (edge_j == kNone)
+            edge_j = 0;
         if (lane == 0) {
-            const uint32_t i = eq / db.n_edges, j = eq - i * db.n_edges;
+            const uint32_t i = edge_i, j = edge_j;
             const uint32_t *ea = t.edges + 2 * (size_t)(da.edge0 + i), *eb = t.edges + 2 * (size_t)(db.edge0 + j);
             const Vec3 a0 = ld3(s.world[0], ea[0]), a1 = ld3(s.world[0], ea[1]);
             const Vec3 b0 = ld3(s.world[1], eb[0]), b1 = ld3(s.world[1], eb[1]);

@@ -100,13 +100,14 @@ struct xpbd_world {
 
     // extension: polytope topology for the body-body narrowphase
     DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
-    DeviceBuffer shape_radii;
+    DeviceBuffer shape_radii, edge_dirs, edge_dir_id;
     bool has_topology = false;
     xpbd::PolytopeTables tables() const
     {
         return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
                                     shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
-                                    face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(), n_shapes};
+                                    face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(),
+                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes};
     }
 
     // extension: contact pipeline (XPBD_MODE_CONTACTS)
@@ -340,7 +341,7 @@ void xpbd_world_destroy(xpbd_world *w)
     for (DeviceBuffer *b : {&w->dyn, &w->stat, &w->shape_id, &w->aos_staging, &w->last_mask, &w->trace,
                             &w->block_counts, &w->contacts, &w->shape_verts, &w->shape_offsets, &w->planes,
                             &w->centroids, &w->shape_desc, &w->face_start, &w->face_verts, &w->edges, &w->pair_buf,
-                            &w->manifold_buf, &w->shape_radii, &w->dyn_alt, &w->cb_centers, &w->cb_radius, &w->cb_cell,
+                            &w->manifold_buf, &w->shape_radii, &w->edge_dirs, &w->edge_dir_id, &w->dyn_alt, &w->cb_centers, &w->cb_radius, &w->cb_cell,
                             &w->cb_key, &w->cb_maxr, &w->cb_bucket_start, &w->cb_bucket_cursor, &w->cb_items,
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
@@ -387,8 +388,8 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
 {
     if (!w || !shapes || n_shapes == 0)
         return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: NULL argument or no shapes");
-    std::vector<double> verts, planes, centroids, radii;
-    std::vector<uint32_t> vert_offsets{0}, face_start{0}, face_verts, edges;
+    std::vector<double> verts, planes, centroids, radii, dirs;
+    std::vector<uint32_t> vert_offsets{0}, face_start{0}, face_verts, edges, dir_id;
     std::vector<xpbd::ShapeDesc> desc;
     for (uint32_t s = 0; s < n_shapes; ++s) {
         const xpbd_polytope &p = shapes[s];
@@ -415,6 +416,26 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
                 return fail(XPBD_E_INVALID, "xpbd_world_set_polytopes: shape %u edge vertex out of range", s);
             edges.push_back(p.edges[e]);
         }
+        // unique edge directions (up to sign), first edge with a direction represents it
+        d.dir0 = (uint32_t)(dirs.size() / 3);
+        for (uint32_t e = 0; e < p.n_edges; ++e) {
+            const xpbd::Vec3 dv = vertex(p.edges[2 * e + 1]) - vertex(p.edges[2 * e]);
+            const uint32_t nd = (uint32_t)(dirs.size() / 3) - d.dir0;
+            uint32_t found = nd;
+            for (uint32_t k = 0; k < nd; ++k) {
+                const double *u = &dirs[3 * (size_t)(d.dir0 + k)];
+                const xpbd::Vec3 uv{u[0], u[1], u[2]};
+                const xpbd::Vec3 c = xpbd::cross(dv, uv);
+                if (xpbd::dot(c, c) <= 1e-12 * (xpbd::dot(dv, dv) * xpbd::dot(uv, uv))) {
+                    found = k;
+                    break;
+                }
+            }
+            if (found == nd)
+                dirs.insert(dirs.end(), {dv.x, dv.y, dv.z});
+            dir_id.push_back(found);
+        }
+        d.n_dirs = (uint32_t)(dirs.size() / 3) - d.dir0;
         const xpbd::Vec3 centroid{p.centroid[0], p.centroid[1], p.centroid[2]};
         for (uint32_t f = 0; f < p.n_faces; ++f) {
             const uint32_t f0 = p.face_offsets[f], f1 = p.face_offsets[f + 1];
@@ -465,6 +486,8 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
     XPBD_HIP_TRY(upload(w->face_verts, face_verts.data(), face_verts.size() * 4));
     XPBD_HIP_TRY(upload(w->edges, edges.data(), edges.size() * 4));
     XPBD_HIP_TRY(upload(w->shape_radii, radii.data(), radii.size() * 8));
+    XPBD_HIP_TRY(upload(w->edge_dirs, dirs.data(), dirs.size() * 8));
+    XPBD_HIP_TRY(upload(w->edge_dir_id, dir_id.data(), dir_id.size() * 4));
     w->has_topology = true;
     return XPBD_OK;
 }

@@ -109,67 +109,126 @@ static void edge_contact(o_frame fa, const o_polytope *pa, uint32_t ea, o_frame 
 }
 
 /*
- * Edge query of the extension.  Same structure, axis orientation, NaN behaviour and first-maximum
- * rule as edge_axes_separation (src/collision.rs:151-197, restated literally in
- * o_edge_axes_separation), with two robustness changes the dead reference code lacks:
- *   - its "another point on `a` is further" test gets a tolerance (OP_SUPPORT_TOL): without one the
- *     edge's own second endpoint beats the foot by rounding noise about half of the time;
- *   - the mirrored test is applied to B's edge, so both edges are supporting features and the
- *     closest points of the two segments really are the contact (the reference only constrains A).
+ * Edge axes of the extension: the classic separating-axis test over the UNIQUE edge directions.
+ * The reference's dead edge_axes_separation (src/collision.rs:151-197, restated literally in
+ * o_edge_axes_separation and pinned by the KATs) enumerates all E_A x E_B edge pairs and re-derives a
+ * support for each; parallel edges give the same axis again and again (a box has 12 edges but 3
+ * directions).  Here every pair (unique direction of A) x (unique direction of B) gives one axis
+ *     n = normalize(dA x dB), flipped to point from A's centroid towards B's,
+ * and its separation is  min_B n.b - max_A n.a  (negative = overlap).  Kept from the reference: the
+ * NaN behaviour for parallel directions (contributes nothing) and the first-maximum rule, now over
+ * (direction of A, direction of B) in ascending order.
  */
-double op_edge_query(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, uint64_t *edge_a,
-                     uint64_t *edge_b)
+#define OP_MAX_DIRS O_MAX_EDGES
+
+/* Unique edge directions (up to sign): dirs[k] = v[e.1] - v[e.0] of the first edge with that direction. */
+uint32_t op_edge_directions(const o_polytope *p, o_vec3 *dirs, uint32_t *dir_of_edge)
+{
+    uint32_t nd = 0;
+    for (uint32_t e = 0; e < p->n_edges; e++) {
+        o_vec3 d = o_sub(p->vertices[p->edges[e][1]], p->vertices[p->edges[e][0]]);
+        uint32_t found = nd;
+        for (uint32_t k = 0; k < nd; k++) {
+            o_vec3 c = o_cross(d, dirs[k]);
+            if (o_dot(c, c) <= 1e-12 * (o_dot(d, d) * o_dot(dirs[k], dirs[k]))) {
+                found = k;
+                break;
+            }
+        }
+        if (found == nd)
+            dirs[nd++] = d;
+        dir_of_edge[e] = found;
+    }
+    return nd;
+}
+
+static int edge_axis(o_frame fa, o_frame fb, o_vec3 dir_a, o_vec3 dir_b, o_vec3 a_to_b, o_vec3 *axis)
+{
+    o_vec3 n = o_normalize(o_cross(o_qrot(fa.rotation, dir_a), o_qrot(fb.rotation, dir_b)));
+    if (!(fabs(n.x) <= DBL_MAX && fabs(n.y) <= DBL_MAX && fabs(n.z) <= DBL_MAX))
+        return 0; /* parallel directions: NaN axis, contributes nothing (as in the reference) */
+    if (o_dot(n, a_to_b) < 0.0)
+        n = o_neg(n);
+    *axis = n;
+    return 1;
+}
+
+double op_edge_query(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, uint64_t *dir_a,
+                     uint64_t *dir_b)
 {
     double max_distance = -DBL_MAX;
-    *edge_a = UINT64_MAX;
-    *edge_b = UINT64_MAX;
-    o_vec3 wa[O_MAX_VERTS], wb[O_MAX_VERTS];
+    *dir_a = UINT64_MAX;
+    *dir_b = UINT64_MAX;
+    o_vec3 wa[O_MAX_VERTS], wb[O_MAX_VERTS], da[OP_MAX_DIRS], db[OP_MAX_DIRS];
+    uint32_t ea[O_MAX_EDGES], eb[O_MAX_EDGES];
     for (uint32_t k = 0; k < pa->n_vertices; k++)
         wa[k] = o_frame_mulv(fa, pa->vertices[k]);
     for (uint32_t k = 0; k < pb->n_vertices; k++)
         wb[k] = o_frame_mulv(fb, pb->vertices[k]);
-    o_vec3 centroid_a = o_frame_mulv(fa, pa->centroid);
-    for (uint32_t ie = 0; ie < pa->n_edges; ie++) {
-        for (uint32_t je = 0; je < pb->n_edges; je++) {
-            o_vec3 foot = wa[pa->edges[ie][0]];
-            o_vec3 e0 = o_sub(wa[pa->edges[ie][1]], foot);
-            o_vec3 b0 = wb[pb->edges[je][0]];
-            o_vec3 e1 = o_sub(wb[pb->edges[je][1]], b0);
-            o_vec3 axis = o_normalize(o_cross(e0, e1));
-            if (!(fabs(axis.x) <= DBL_MAX && fabs(axis.y) <= DBL_MAX && fabs(axis.z) <= DBL_MAX))
-                continue; /* parallel edges: NaN axis, contributes nothing (as in the reference) */
-            if (o_dot(axis, o_sub(foot, centroid_a)) < 0.0)
-                axis = o_neg(axis);
-            double reach = o_dot(wa[0], axis);
+    uint32_t nda = op_edge_directions(pa, da, ea), ndb = op_edge_directions(pb, db, eb);
+    o_vec3 a_to_b = o_sub(o_frame_mulv(fb, pb->centroid), o_frame_mulv(fa, pa->centroid));
+    for (uint32_t i = 0; i < nda; i++) {
+        for (uint32_t j = 0; j < ndb; j++) {
+            o_vec3 axis;
+            if (!edge_axis(fa, fb, da[i], db[j], a_to_b, &axis))
+                continue;
+            double reach_a = o_dot(wa[0], axis), reach_b = o_dot(wb[0], axis);
             for (uint32_t k = 1; k < pa->n_vertices; k++) {
                 double r = o_dot(wa[k], axis);
-                if (r > reach)
-                    reach = r;
+                if (r > reach_a)
+                    reach_a = r;
             }
-            if (reach > o_dot(foot, axis) + OP_SUPPORT_TOL)
-                continue;
-            o_vec3 nax = o_neg(axis);
-            o_vec3 sup = wb[0];
-            double breach = o_dot(sup, nax);
             for (uint32_t k = 1; k < pb->n_vertices; k++) {
-                double r = o_dot(wb[k], nax);
-                if (r >= breach) { /* last maximum, as Polytope::support */
-                    breach = r;
-                    sup = wb[k];
-                }
+                double r = o_dot(wb[k], axis);
+                if (r < reach_b)
+                    reach_b = r;
             }
-            if (breach > o_dot(b0, nax) + OP_SUPPORT_TOL)
-                continue;
-            o_plane plane = o_plane_from_point_normal(foot, axis);
-            double distance = o_plane_distance(plane, sup);
+            double distance = reach_b - reach_a;
             if (distance > max_distance) {
                 max_distance = distance;
-                *edge_a = ie;
-                *edge_b = je;
+                *dir_a = i;
+                *dir_b = j;
             }
         }
     }
     return max_distance;
+}
+
+/* Supporting edges of the chosen edge axis: A's edge of direction dir_a furthest along the axis, B's edge of
+ * direction dir_b furthest against it (sum of the two endpoint projections; first extremum). */
+static void supporting_edges(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, uint32_t dir_a,
+                             uint32_t dir_b, uint32_t *edge_a, uint32_t *edge_b)
+{
+    o_vec3 da[OP_MAX_DIRS], db[OP_MAX_DIRS], axis;
+    uint32_t ea[O_MAX_EDGES], eb[O_MAX_EDGES];
+    op_edge_directions(pa, da, ea);
+    op_edge_directions(pb, db, eb);
+    o_vec3 a_to_b = o_sub(o_frame_mulv(fb, pb->centroid), o_frame_mulv(fa, pa->centroid));
+    edge_axis(fa, fb, da[dir_a], db[dir_b], a_to_b, &axis);
+    double best = -DBL_MAX;
+    *edge_a = 0;
+    for (uint32_t e = 0; e < pa->n_edges; e++) {
+        if (ea[e] != dir_a)
+            continue;
+        double sproj = o_dot(o_frame_mulv(fa, pa->vertices[pa->edges[e][0]]), axis)
+                     + o_dot(o_frame_mulv(fa, pa->vertices[pa->edges[e][1]]), axis);
+        if (sproj > best) {
+            best = sproj;
+            *edge_a = e;
+        }
+    }
+    best = DBL_MAX;
+    *edge_b = 0;
+    for (uint32_t e = 0; e < pb->n_edges; e++) {
+        if (eb[e] != dir_b)
+            continue;
+        double sproj = o_dot(o_frame_mulv(fb, pb->vertices[pb->edges[e][0]]), axis)
+                     + o_dot(o_frame_mulv(fb, pb->vertices[pb->edges[e][1]]), axis);
+        if (sproj < best) {
+            best = sproj;
+            *edge_b = e;
+        }
+    }
 }
 
 void op_sat(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, op_manifold *out)
@@ -209,10 +268,12 @@ void op_sat(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, 
     out->separated = 0;
     out->separation = m;
     if (use_edges) {
+        uint32_t sup_a, sup_b;
+        supporting_edges(fa, fb, pa, pb, (uint32_t)edge_a, (uint32_t)edge_b, &sup_a, &sup_b);
         out->feature = OP_FEATURE_EDGES;
-        out->index_a = (uint32_t)edge_a;
-        out->index_b = (uint32_t)edge_b;
-        edge_contact(fa, pa, (uint32_t)edge_a, fb, pb, (uint32_t)edge_b, out);
+        out->index_a = sup_a;
+        out->index_b = sup_b;
+        edge_contact(fa, pa, sup_a, fb, pb, sup_b, out);
     } else if (qa == m) {
         out->feature = OP_FEATURE_FACE_A;
         out->index_a = (uint32_t)face_a;

@@ -10,7 +10,8 @@
  * extension's semantics; there is no reference output to compare with.
  * What IS taken from the reference (and pinned by tests/test_oracle_kat.py):
  *   face_axes_separation   src/collision.rs:123-149  (last-max support, first-max face)
- *   edge_axes_separation   src/collision.rs:151-197  (axis orientation, skip rule, NaN for parallel edges)
+ *   edge_axes_separation   src/collision.rs:151-197  (NaN for parallel edges, first maximum; the pair enumeration is
+ *                          replaced by the classic test over unique edge directions, see op_edge_query)
  *   feature choice         src/collision.rs:47-59,89-92 (comments): separated if any query >= 0;
  *                          reference face on A if a == max(a, b, e), else on B if b == max, else edge-edge
  *   reference plane        src/collision.rs:66       frames.0 * polytopes.0.plane(face)
@@ -29,8 +30,6 @@ extern "C" {
 #define OP_MAX_POINTS 8
 /* The edge-edge axis is used only if it separates better than both face axes by this much (m). */
 #define OP_EDGE_BIAS 1e-6
-/* Slack of the "is this edge a supporting feature" tests of the edge query (m). */
-#define OP_SUPPORT_TOL 1e-9
 
 #define OP_FEATURE_FACE_A 0
 #define OP_FEATURE_FACE_B 1
@@ -49,8 +48,11 @@ typedef struct {
 } op_manifold;
 /* Reference body: A for FACE_A and EDGES, B for FACE_B.  Incident body: the other one. */
 
-double op_edge_query(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, uint64_t *edge_a,
-                     uint64_t *edge_b);
+/* unique edge directions of a polytope (up to sign) and the direction index of every edge; returns their number */
+uint32_t op_edge_directions(const o_polytope *p, o_vec3 *dirs, uint32_t *dir_of_edge);
+/* separating-axis test over (unique direction of A) x (unique direction of B); returns the largest separation */
+double op_edge_query(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, uint64_t *dir_a,
+                     uint64_t *dir_b);
 void op_sat(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, op_manifold *out);
 
 /* ---------------------------------------------------------------------------
