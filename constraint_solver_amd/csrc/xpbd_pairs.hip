@@ -383,7 +383,8 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
 __global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pairs, unsigned long long *__restrict__ stats)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t points = p < n_pairs ? m[p].n_points : 0u;
+    // n_points is the first word of a 408-byte record: a strided read, but only 4 of every 408 bytes
+    uint32_t points = p < n_pairs ? __builtin_nontemporal_load(&m[p].n_points) : 0u;
     uint32_t touching = points ? 1u : 0u;
     for (uint32_t off = 32; off; off >>= 1) {
         points += __shfl_xor(points, off, 64);
