@@ -378,14 +378,19 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     m->separation = face_best;
 }
 
-// stats[0] += pairs with contact points, stats[1] += contact points.  One atomic pair per BLOCK:
-// same-address atomics serialise at the memory side (~10 ns each), so they must not be per pair.
+// stats[0] += pairs with contact points, stats[1] += contact points.  Same-address atomics serialise at
+// the memory side (~10 ns each): never one per pair (that WAS the whole narrowphase launch once), and
+// not even one per 256 pairs -- a grid-stride loop over at most kStatsBlocks blocks, one atomic pair each.
+constexpr uint32_t kStatsBlocks = 128;
+
 __global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pairs, unsigned long long *__restrict__ stats)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    // n_points is the first word of a 408-byte record: a strided read, but only 4 of every 408 bytes
-    uint32_t points = p < n_pairs ? __builtin_nontemporal_load(&m[p].n_points) : 0u;
-    uint32_t touching = points ? 1u : 0u;
+    uint32_t points = 0, touching = 0;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
+        const uint32_t n = m[p].n_points;
+        points += n;
+        touching += n ? 1u : 0u;
+    }
     for (uint32_t off = 32; off; off >>= 1) {
         points += __shfl_xor(points, off, 64);
         touching += __shfl_xor(touching, off, 64);
@@ -406,8 +411,10 @@ __global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pair
 
 hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream)
 {
-    if (n_pairs && stats)
-        hipLaunchKernelGGL(k_manifold_stats, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, m, n_pairs, stats);
+    if (n_pairs && stats) {
+        const uint32_t nb = (n_pairs + 255) / 256;
+        hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, m, n_pairs, stats);
+    }
     return hipGetLastError();
 }
 
@@ -416,8 +423,10 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
 {
     if (n_pairs) {
         hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
-        if (stats)
-            hipLaunchKernelGGL(k_manifold_stats, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, out, n_pairs, stats);
+        if (stats) {
+            const uint32_t nb = (n_pairs + 255) / 256;
+            hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);
+        }
     }
     return hipGetLastError();
 }
