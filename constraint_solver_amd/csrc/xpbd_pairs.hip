@@ -69,7 +69,8 @@ __device__ __forceinline__ Vec3 support_last_max(const double (*verts)[3], uint3
     return best;
 }
 
-// (value, index) reductions.  `width` lanes (32 or 64) starting at aligned groups.
+// (value, index) reductions over `width` consecutive lanes (a power of two; xor offsets < width stay inside
+// the aligned group).
 __device__ __forceinline__ void reduce_max_first(double &v, uint32_t &idx, uint32_t width)
 {
     for (uint32_t off = width >> 1; off; off >>= 1) {
@@ -96,18 +97,27 @@ __device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint3
 
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
+// L = lanes per pair: 64 (one pair per wave; any shapes), 32, or 16 (FOUR pairs per wave: for boxes every stage --
+// 8 + 8 vertices, 6 + 6 faces, 3 x 3 edge axes, <= 16 polygon points -- fits in 16 lanes, so a whole wave per
+// pair would idle 3/4 of its lanes).  All loops stride by the group width and all shuffles stay inside the
+// group, so both instantiations produce the same bits.  The block is ONE wave, hence __syncthreads() is a
+// wave-local fence and the sub-waves of a wave may diverge freely (one pair separated, the next one clipping).
+template <uint32_t L>
 __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                   Manifold *__restrict__ out)
 {
-    __shared__ PairLds s;
-    const uint32_t p = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
+    constexpr uint32_t H = L / 2;        // lanes per body in the two-sided stages
+    constexpr uint32_t PW = 64 / L;      // pairs per wave
+    __shared__ PairLds s_all[PW];
+    PairLds &s = s_all[threadIdx.x / L];
+    const uint32_t p = blockIdx.x * PW + threadIdx.x / L;
+    const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
     if (p >= n_pairs)
         return;
 
-    // ---- wave-uniform inputs -------------------------------------------------------------------
-    const uint32_t ia = pairs[2 * p], ib = pairs[2 * p + 1];
+    // ---- group-uniform inputs ---------------------------------------------------------------------
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
     const Frame fa_inv = inverse(fa), fb_inv = inverse(fb);
     const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
@@ -121,45 +131,45 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     }
 
     // ---- both vertex sets into LDS: world space, and the other body's local space -----------------
-    const uint32_t half = lane >> 5, k = lane & 31u; // lanes 0-31 work for A, 32-63 for B
+    const uint32_t half = lane / H, k = lane % H; // first half of the group works for A, second for B
     {
         const ShapeDesc dm = half ? db : da;
-        if (k < dm.n_verts) {
-            const double *v = t.verts + 3 * (size_t)(dm.vert0 + k);
+        for (uint32_t vtx = k; vtx < dm.n_verts; vtx += H) {
+            const double *v = t.verts + 3 * (size_t)(dm.vert0 + vtx);
             const Vec3 w = (half ? fb : fa) * Vec3{v[0], v[1], v[2]};
-            st3(s.world[half], k, w);
-            st3(s.local[half], k, (half ? fa_inv : fb_inv) * w); // frames.0.inverse() * (frames.1 * p), :136-137
+            st3(s.world[half], vtx, w);
+            st3(s.local[half], vtx, (half ? fa_inv : fb_inv) * w); // frames.0.inverse() * (frames.1 * p), :136-137
         }
     }
     __syncthreads();
 
-    // ---- face queries (src/collision.rs:123-149), A's faces on lanes 0-31, B's on lanes 32-63 -----
+    // ---- face queries (src/collision.rs:123-149): A's faces on the first half, B's on the second -------
     double fdist = -DBL_MAX;
     uint32_t fidx = kNone;
     {
         const ShapeDesc dm = half ? db : da;
         const uint32_t n_other = half ? da.n_verts : db.n_verts;
-        if (k < dm.n_faces) {
-            const double *pl = t.planes + 4 * (size_t)(dm.face0 + k);
+        for (uint32_t f = k; f < dm.n_faces; f += H) {
+            const double *pl = t.planes + 4 * (size_t)(dm.face0 + f);
             const Vec3 n{pl[0], pl[1], pl[2]};
             const Vec3 sup = support_last_max(s.local[half ^ 1u], n_other, -n);
             const double dist = dot(n, sup) - pl[3];
-            if (dist > -DBL_MAX) { // a NaN distance never beats f64::MIN, as `distance > max_distance`
+            if (dist > fdist) { // ascending f on this lane: first maximum; a NaN never beats f64::MIN
                 fdist = dist;
-                fidx = k;
+                fidx = f;
             }
         }
     }
-    reduce_max_first(fdist, fidx, 32);
-    const double qa = __shfl(fdist, 0, 64), qb = __shfl(fdist, 32, 64);
-    const uint32_t face_a = __shfl(fidx, 0, 64), face_b = __shfl(fidx, 32, 64);
+    reduce_max_first(fdist, fidx, H);
+    const double qa = __shfl(fdist, 0, L), qb = __shfl(fdist, H, L);
+    const uint32_t face_a = __shfl(fidx, 0, L), face_b = __shfl(fidx, H, L);
     if (qa >= 0.0 || qb >= 0.0 || face_a == kNone || face_b == kNone) {
         if (lane == 0)
             m->n_points = 0;
         return;
     }
 
-    // ---- edge axes: (unique edge direction of A) x (unique edge direction of B), strided over the lanes ----
+    // ---- edge axes: (unique edge direction of A) x (unique edge direction of B), strided over the group ----
     // n = normalize(dA x dB) pointing from A's centroid to B's; separation = min_B n.b - max_A n.a.
     // Parallel directions give a NaN axis and contribute nothing; first maximum wins (ascending pair index).
     double ebest = -DBL_MAX;
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     };
     {
         const uint32_t total = da.n_dirs * db.n_dirs;
-        for (uint32_t q = lane; q < total; q += 64) {
+        for (uint32_t q = lane; q < total; q += L) {
             const uint32_t i = q / db.n_dirs, j = q - i * db.n_dirs;
             Vec3 axis;
             if (!edge_axis(i, j, axis))
@@ -201,7 +211,7 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
             }
         }
     }
-    reduce_max_first(ebest, eq, 64);
+    reduce_max_first(ebest, eq, L);
     if (ebest >= 0.0) {
         if (lane == 0)
             m->n_points = 0;
@@ -214,13 +224,13 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
 
     if (use_edges) {
         // supporting edges of the winning axis: A's edge of that direction furthest along the axis, B's edge
-        // furthest against it (sum of the endpoint projections, first extremum); one edge per lane
+        // furthest against it (sum of the endpoint projections, first extremum); edges strided over the group
         const uint32_t di = eq / db.n_dirs, dj = eq - di * db.n_dirs;
         Vec3 axis;
         (void)edge_axis(di, dj, axis);
         double sa_best = -DBL_MAX, sb_best = DBL_MAX;
         uint32_t edge_i = kNone, edge_j = kNone;
-        for (uint32_t e = lane; e < da.n_edges; e += 64) {
+        for (uint32_t e = lane; e < da.n_edges; e += L) {
             if (t.edge_dir_id[da.edge0 + e] != di)
                 continue;
             const uint32_t *ev = t.edges + 2 * (size_t)(da.edge0 + e);
@@ -230,7 +240,7 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
                 edge_i = e;
             }
         }
-        for (uint32_t e = lane; e < db.n_edges; e += 64) {
+        for (uint32_t e = lane; e < db.n_edges; e += L) {
             if (t.edge_dir_id[db.edge0 + e] != dj)
                 continue;
             const uint32_t *ev = t.edges + 2 * (size_t)(db.edge0 + e);
@@ -240,8 +250,8 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
                 edge_j = e;
             }
         }
-        reduce_max_first(sa_best, edge_i, 64);
-        reduce_min_first(sb_best, edge_j, 64);
+        reduce_max_first(sa_best, edge_i, L);
+        reduce_min_first(sb_best, edge_j, L);
         if (edge_i == kNone)
             edge_i = 0;
         if (edge_j == kNone)
@@ -283,24 +293,24 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     const double *rp = t.planes + 4 * (size_t)(dr.face0 + ref_face);
     const Plane ref_plane = fr * Plane{Vec3{rp[0], rp[1], rp[2]}, rp[3]}; // frames.0 * polytopes.0.plane(face), :66
 
-    // incident face: least normal . ref_normal, first minimum (:76-85); one face per lane
+    // incident face: least normal . ref_normal, first minimum (:76-85); faces strided over the group
     double idot = DBL_MAX;
     uint32_t iface = kNone;
-    if (lane < di.n_faces) {
-        const double *pl = t.planes + 4 * (size_t)(di.face0 + lane);
+    for (uint32_t f = lane; f < di.n_faces; f += L) {
+        const double *pl = t.planes + 4 * (size_t)(di.face0 + f);
         const Plane w = fi * Plane{Vec3{pl[0], pl[1], pl[2]}, pl[3]};
         const double d = dot(w.normal, ref_plane.normal);
-        if (d < DBL_MAX) {
+        if (d < idot) { // ascending f on this lane: first minimum
             idot = d;
-            iface = lane;
+            iface = f;
         }
     }
-    reduce_min_first(idot, iface, 64);
+    reduce_min_first(idot, iface, L);
     if (iface == kNone)
         iface = 0;
 
     // Sutherland-Hodgman with ONE POLYGON VERTEX PER LANE (polygons have <= 16 vertices): every lane
-    // tests its edge (p0 -> p1) against the side plane, a wave prefix sum of the 0/1/2 points it emits
+    // tests its edge (p0 -> p1) against the side plane, a prefix sum of the 0/1/2 points it emits
     // gives their slots, so the output order is exactly that of the sequential algorithm.
     const uint32_t *rv = t.face_verts + t.face_start[dr.face0 + ref_face];
     const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
@@ -331,11 +341,11 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
         uint32_t inc = emit;
 #pragma unroll
         for (uint32_t d = 1; d < 16; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
+            const uint32_t up = __shfl_up(inc, d, L);
             if (lane >= d)
                 inc += up;
         }
-        const uint32_t total = __shfl(inc, 15, 64);
+        const uint32_t total = __shfl(inc, 15, L);
         uint32_t slot = inc - emit;
         if (in0 && slot < 16)
             st3(s.poly[cur ^ 1u], slot++, p0);
@@ -357,11 +367,11 @@ __global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t
     uint32_t inc = keep ? 1u : 0u;
 #pragma unroll
     for (uint32_t d = 1; d < 16; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, 64);
+        const uint32_t up = __shfl_up(inc, d, L);
         if (lane >= d)
             inc += up;
     }
-    const uint32_t kept = __shfl(inc, 15, 64);
+    const uint32_t kept = __shfl(inc, 15, L);
     const uint32_t n_out = kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
     if (keep && inc - 1 < kMaxManifoldPoints) {
         const uint32_t at = inc - 1;
@@ -422,7 +432,14 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
                             uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream)
 {
     if (n_pairs) {
-        hipLaunchKernelGGL(k_sat_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        // lanes per pair by the largest shape: 16 (four pairs per wave) when every shape has <= 8 vertices and
+        // faces (boxes, tetrahedra), 32 (two pairs per wave) up to 16 vertices (icosahedra), else a whole wave
+        if (t.lanes_per_pair == 16)
+            hipLaunchKernelGGL(k_sat_pairs<16>, dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        else if (t.lanes_per_pair == 32)
+            hipLaunchKernelGGL(k_sat_pairs<32>, dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        else
+            hipLaunchKernelGGL(k_sat_pairs<64>, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         if (stats) {
             const uint32_t nb = (n_pairs + 255) / 256;
             hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);
