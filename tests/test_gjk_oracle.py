@@ -69,3 +69,22 @@ def test_exactly_touching_faces_are_not_penetrating():
     h = math.radians(45) / 2
     r = ob.gjk_epa(([0, 0, 0], I4), ([1.3, 0.5, 0.2], [math.cos(h), 0, 0, math.sin(h)]), CUBE, CUBE)
     assert r.status == ob.GJK_PENETRATING and abs(r.depth - 0.1414213562373) < 1e-9
+
+
+def test_random_convex_hulls_sat_equals_epa():
+    """Shapes beyond the reference's three: random 16-vertex hulls (28 faces, 42 edges, all directions distinct)."""
+    import hull_util as hu
+    hulls = [hu.as_oracle(*hu.random_hull(s)) for s in (1, 2, 3)]
+    rng = np.random.default_rng(9)
+    hits = 0
+    for _ in range(400):
+        pa, pb = hulls[rng.integers(3)], hulls[rng.integers(3)]
+        fa = (rng.uniform(-0.2, 0.2, 3), rand_quat(rng))
+        fb = (rng.uniform(-0.7, 0.7, 3), rand_quat(rng))
+        m, r = ob.sat(fa, fb, pa, pb), ob.gjk_epa(fa, fb, pa, pb)
+        assert r.status != ob.GJK_DEGENERATE
+        assert (r.status == ob.GJK_PENETRATING) == (not m.separated)
+        if r.status == ob.GJK_PENETRATING:
+            hits += 1
+            assert abs(r.depth + max(m.query)) < 1e-9
+    assert hits > 100

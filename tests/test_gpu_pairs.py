@@ -431,3 +431,39 @@ def test_contact_pipeline_with_gjk_epa_narrowphase_matches_oracle():
     for _ in range(30):
         sat_want, _, _ = ob.contacts_step(sat_want, sid, polys, DT, 10, 0.02)
     assert not bits_equal(sat_want, want)
+
+
+def test_narrowphases_on_random_convex_hulls():
+    """Shape-generic check (32 lanes per pair): random 16-vertex hulls through both narrowphase kernels vs the oracle."""
+    import hull_util as hu
+    raw = [hu.random_hull(s) for s in (1, 2, 3)]
+    oracle_polys = [hu.as_oracle(*h) for h in raw]
+    n = 90
+    bodies, _ = capi.scene_generate(capi.SCENE_BOXES, 2, n)
+    rng = np.random.default_rng(15)
+    bodies[:, 31:34] = rng.uniform(-0.8, 0.8, (n, 3))
+    bodies[:, 28:31] = 0.0                                          # the hulls are centred: com = 0
+    sid = (np.arange(n) % 3).astype(np.uint32)
+    pairs = rng.integers(0, n, (1500, 2)).astype(np.uint32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    with capi.World() as w:
+        w.set_polytopes([hu.as_capi(*h) for h in raw])
+        w.upload(bodies, sid)
+        sat = w.narrowphase(pairs)
+        gjk = w.narrowphase_gjk(pairs)
+    L = ob.load()
+    frames = []
+    for b in bodies:
+        f = L.o_rigid_frame(C.byref(ob.Rigid.from_np(b)))
+        frames.append((f.position.np(), f.rotation.np()))
+    want = [ob.sat(frames[i], frames[j], oracle_polys[int(sid[i])], oracle_polys[int(sid[j])]) for i, j in pairs]
+    feats = assert_same(sat, want)
+    assert {0, 1} <= feats
+    hits = 0
+    for g, (i, j) in zip(gjk, pairs):
+        r = ob.gjk_epa(frames[i], frames[j], oracle_polys[int(sid[i])], oracle_polys[int(sid[j])])
+        assert (g["status"], g["gjk_iterations"], g["epa_iterations"]) == (r.status, r.gjk_iterations, r.epa_iterations)
+        if r.status == ob.GJK_PENETRATING:
+            hits += 1
+            assert bits_equal(np.array([g["depth"]]), np.array([r.depth])) and bits_equal(g["point_a"], r.point_a.np())
+    assert hits > 200
