@@ -91,7 +91,8 @@ def run_contacts_sharded(args, capi, kind, rank, local_rank, world_size):
     radius = np.array([np.linalg.norm(p["vertices"] - p["centroid"], axis=1).max() for p in polys])
     centroid = np.array([p["centroid"] for p in polys])
     backend = GpuBackend(capi, polys, 0.02, device=local_rank)
-    world = ShardedContactWorld(backend, rank, world_size, bodies, shape_id, radius, centroid, pad=0.02, halo_margin=0.5)
+    world = ShardedContactWorld(backend, rank, world_size, bodies, shape_id, radius, centroid, pad=0.02, halo_margin=0.5,
+                                order=args.order)
     for _ in range(args.warmup):
         world.step(FRAME_TIME, args.substeps)
     torch.cuda.synchronize()
@@ -113,6 +114,7 @@ def run_contacts_sharded(args, capi, kind, rank, local_rank, world_size):
             "config": {"workload": "EXTENSION body-body contacts: %d unit boxes per GPU x %d substeps/frame, scene '%s'"
                                    % (args.bodies, args.substeps, args.scene),
                        "bodies_per_gpu": args.bodies, "bodies_total": total, "substeps": args.substeps, "mode": "contacts",
+                       "order": args.order,
                        "sharding": "body-index ranges + ghost bodies; halo all-gather after every substep (%s)"
                                    % dist.get_backend(),
                        "halo_bodies_rank0": int(len(world.plan.ghosts[0])), "boundary_capacity": int(world.plan.capacity),
@@ -145,6 +147,8 @@ def main():
                     help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (one point per pair)")
     ap.add_argument("--joints", type=int, default=0,
                     help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
+    ap.add_argument("--order", default="index", choices=["index", "spatial"],
+                    help="contacts mode, N > 1: shard the caller's index ranges, or renumber bodies by grid cell first")
     ap.add_argument("--pitch", type=float, default=2.0,
                     help="grid pitch of the scene in metres (generator default 2.0); < 2 packs bodies so that they collide")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -7,7 +7,10 @@ with tests/halo_common.OracleBackend standing in for the device) and tests/test_
 
 Scheme
 ------
-* Ownership: contiguous global index ranges (sharding.shard_range), as for the pinned path.
+* Ownership: contiguous index ranges (sharding.shard_range), as for the pinned path -- of the caller's
+  body order (order="index") or of the bodies sorted by spatial-hash cell (order="spatial": x-major
+  cell order, so every rank owns a slab of space and the halos are thin).  The spatial order is a
+  renumbering: results equal a single-device run over the same renumbered bodies, bit for bit.
 * Every rank's world holds OWNED bodies plus GHOST copies of remote bodies that can reach an
   owned body before the next re-plan; the local order is ascending global id, so every
   neighbour list and every floating-point sum has the same order as on a single device.
@@ -17,8 +20,10 @@ Scheme
   is incomplete), and that is overwritten with the owner's result:
       export owned boundary bodies (13 doubles each) -> all_gather -> import into the ghosts.
 * The halo is static between re-plans: `halo_margin` is how far any body may travel before
-  `replan()` must be called (re-gathers the whole state on the host; O(N) and not on the
-  per-substep path).
+  `replan()` must be called (`replan_every=k` does it every k frames; it re-gathers the whole state
+  on the host, O(N), not on the per-substep path).  A body that outruns the margin -- e.g. one
+  flung out of a deep initial overlap at 100 m/s -- silently misses contacts with remote bodies,
+  exactly as a too small broadphase margin would; size the margin for the scene's speeds.
 """
 import numpy as np
 
@@ -37,6 +42,15 @@ def bounding_spheres(bodies, shape_id, shape_radius, shape_centroid):
     sid = np.asarray(shape_id, dtype=np.int64)
     radius = np.asarray(shape_radius)[sid] + np.linalg.norm(np.asarray(shape_centroid)[sid] - com, axis=1)
     return centre, radius
+
+
+def spatial_order(bodies, shape_id, shape_radius, shape_centroid, pad, halo_margin):
+    """Permutation that sorts the bodies by spatial-hash cell, x-major (then y, z, then index): contiguous index
+    ranges of the sorted bodies are slabs of space.  Same cell edge as HaloPlan."""
+    centre, radius = bounding_spheres(bodies, shape_id, shape_radius, shape_centroid)
+    edge = 2.0 * (float(radius.max()) + pad + halo_margin) if len(bodies) else 1.0
+    cell = np.floor(centre / edge).astype(np.int64)
+    return np.lexsort((np.arange(len(bodies)), cell[:, 2], cell[:, 1], cell[:, 0]))
 
 
 class HaloPlan:
@@ -147,13 +161,25 @@ class ShardedContactWorld:
     """One rank of an N-body world with body-body contacts sharded over `world_size` processes."""
 
     def __init__(self, backend, rank, world_size, bodies_global, shape_id_global, shape_radius, shape_centroid,
-                 pad=0.02, halo_margin=0.5, group=None, joints_global=None):
+                 pad=0.02, halo_margin=0.5, group=None, joints_global=None, order="index", replan_every=0):
         self.backend, self.rank, self.world_size, self.group = backend, rank, world_size, group
+        self.replan_every, self._frames = replan_every, 0   # > 0: re-select the halos every that many step() calls
         self.pad, self.halo_margin = pad, halo_margin
         self.shape_radius, self.shape_centroid = shape_radius, shape_centroid
-        self.shape_id_global = np.asarray(shape_id_global, dtype=np.uint32)
-        self.joints_global = joints_global          # records with body_a / body_b as GLOBAL ids (capi.JOINT_DTYPE)
-        self._plan(np.asarray(bodies_global, dtype=np.float64))
+        bodies_global = np.asarray(bodies_global, dtype=np.float64)
+        shape_id_global = np.asarray(shape_id_global, dtype=np.uint32)
+        # `perm[k]` = caller's index of the body that is number k internally
+        self.perm = spatial_order(bodies_global, shape_id_global, shape_radius, shape_centroid, pad, halo_margin) \
+            if order == "spatial" else np.arange(bodies_global.shape[0])
+        inverse = np.empty_like(self.perm)
+        inverse[self.perm] = np.arange(len(self.perm))
+        self.shape_id_global = shape_id_global[self.perm]
+        if joints_global is not None and len(joints_global):
+            joints_global = joints_global.copy()    # records with body_a / body_b as ids (capi.JOINT_DTYPE)
+            joints_global["body_a"] = inverse[joints_global["body_a"]]
+            joints_global["body_b"] = inverse[joints_global["body_b"]]
+        self.joints_global = joints_global
+        self._plan(bodies_global[self.perm])
 
     def _plan(self, bodies_global):
         centre, radius = bounding_spheres(bodies_global, self.shape_id_global, self.shape_radius, self.shape_centroid)
@@ -195,6 +221,9 @@ class ShardedContactWorld:
 
     def step(self, dt, substeps):
         """xpbd_world_step(dt, substeps) of the whole sharded world (lock step over ranks)."""
+        if self.replan_every and self._frames and self._frames % self.replan_every == 0:
+            self.replan()
+        self._frames += 1
         h = dt / float(substeps)
         self.backend.begin(dt)
         for _ in range(substeps):
@@ -223,6 +252,14 @@ class ShardedContactWorld:
         dist.all_gather(parts, mine, group=self.group)
         return np.concatenate([parts[r][: self.plan.owned[r][1]].cpu().numpy() for r in range(self.world_size)])
 
+    def gather_global_in_caller_order(self):
+        """gather_global() mapped back from the internal (possibly spatial) numbering to the caller's body order."""
+        state = self.gather_global()
+        out = np.empty_like(state)
+        out[self.perm] = state
+        return out
+
     def replan(self):
-        """Re-select the halos from the current positions (call before any body has moved halo_margin)."""
+        """Re-select the halos from the current positions (call before any body has moved halo_margin).
+        The numbering (and with it the ownership) is kept; only the ghost sets change."""
         self._plan(self.gather_global())

@@ -85,6 +85,15 @@ def pile(capi, kind, n, seed, width, height):
     return bodies, sid
 
 
+def line_scene(capi, kind, n, seed, pitch):
+    """A long, two-row grid of dropped bodies at `pitch` metres: no initial overlaps, bodies land, tumble and
+    bump into their neighbours at a few m/s -- a scene that respects a sub-metre halo margin."""
+    bodies, sid = capi.scene_generate(kind, seed, n, grid_w=max(n // 2, 1))
+    bodies[:, 31:33] *= pitch / 2.0
+    bodies[:, 22:25] *= 0.3
+    return bodies, sid
+
+
 def shape_tables(capi, kind):
     polys = capi.scene_polytopes(kind)
     radius = np.array([np.linalg.norm(p["vertices"] - p["centroid"], axis=1).max() for p in polys])
@@ -92,12 +101,13 @@ def shape_tables(capi, kind):
     return polys, radius, centroid
 
 
-def chain_joints(capi, n, every=3):
-    """Distance joints between body k and k + every (so they cross shard boundaries), face-centre anchors."""
-    a = np.arange(0, n - every, 2)
+def chain_joints(capi, n, every=3, distance=1.5, limit=None):
+    """Distance joints between body k and k + every (so they cross shard boundaries), centre anchors;
+    `limit` keeps both ends below that index (one row of line_scene)."""
+    a = np.arange(0, (limit or n) - every, 2)
     j = np.zeros(len(a), dtype=capi.JOINT_DTYPE)
     j["body_a"], j["body_b"] = a, a + every
-    j["anchor_a"], j["anchor_b"], j["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], 1.5
+    j["anchor_a"], j["anchor_b"], j["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], distance
     return j
 
 
@@ -113,7 +123,7 @@ def expected(ob, bodies, sid, kind, substeps, frames, pad, joints=None):
 
 
 def worker(rank, world_size, port, out_dir, backend_name, kind, n, seed, width, substeps, frames, pad, replan_at,
-           with_joints=False):
+           with_joints=False, order="index"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -123,24 +133,27 @@ def worker(rank, world_size, port, out_dir, backend_name, kind, n, seed, width, 
     from constraint_solver_amd.distributed import GpuBackend, ShardedContactWorld
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
-        bodies, sid = pile(capi, kind, n, seed, width, 6.0)
+        bodies, sid = line_scene(capi, kind, n, seed, -width) if width < 0 else pile(capi, kind, n, seed, width, 6.0)
         polys, radius, centroid = shape_tables(capi, kind)
         if backend_name == "gpu":
             backend = GpuBackend(capi, polys, pad, device=0)     # rehearsal: every rank on the one GPU of the box
         else:
             import oracle_binding as ob
             backend = OracleBackend(ob, POLY_NAMES[kind], pad)
-        joints = chain_joints(capi, n) if with_joints else None
+        # with_joints: False, True (the default chain) or the keyword arguments of chain_joints
+        joints = chain_joints(capi, n, **(with_joints if isinstance(with_joints, dict) else {})) if with_joints else None
         world = ShardedContactWorld(backend, rank, world_size, bodies, sid, radius, centroid, pad=pad, halo_margin=0.75,
-                                    joints_global=joints)
+                                    joints_global=joints, order=order)
         assert sum(len(g) for g in world.plan.ghosts) > 0         # the case does have halos
         for f in range(frames):
             if f == replan_at:
                 world.replan()
             world.step(DT, substeps)
-        state = world.gather_global()
+        state = world.gather_global_in_caller_order()
         if rank == 0:
             np.save(os.path.join(out_dir, "sharded.npy"), state)
+            np.save(os.path.join(out_dir, "perm.npy"), world.perm)
+            np.save(os.path.join(out_dir, "ghosts.npy"), np.array([len(g) for g in world.plan.ghosts]))
         backend.close()
     finally:
         dist.destroy_process_group()

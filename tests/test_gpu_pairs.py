@@ -338,6 +338,35 @@ def test_sharded_gpu_world_with_joints_equals_single_gpu(tmp_path):
     assert bits_equal(got, hc.expected(ob, bodies, sid, kind, substeps, frames, pad, hc.chain_joints(capi, n)))
 
 
+def test_spatially_ordered_sharded_gpu_world_equals_single_gpu(tmp_path):
+    """Three ranks (all on the one GPU of the box), bodies renumbered by grid cell so each rank owns a slab and mirrors
+    a thin halo; joints along one row; == the oracle's single run over the renumbered bodies, in the caller's order."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    import halo_common as hc
+    kind, n, seed, pitch, substeps, frames, pad = capi.SCENE_BOXES_DROP, 150, 5, 1.15, 8, 8, 0.02
+    chain = dict(every=1, distance=pitch, limit=n // 2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(hc.worker, args=(3, port, str(tmp_path), "gpu", kind, n, seed, -pitch, substeps, frames, pad, 4, chain, "spatial"),
+             nprocs=3, join=True)
+    got, perm, ghosts = np.load(tmp_path / "sharded.npy"), np.load(tmp_path / "perm.npy"), np.load(tmp_path / "ghosts.npy")
+    bodies, sid = hc.line_scene(capi, kind, n, seed, pitch)
+    joints = hc.chain_joints(capi, n, **chain)
+    inverse = np.empty_like(perm)
+    inverse[perm] = np.arange(n)
+    joints["body_a"], joints["body_b"] = inverse[joints["body_a"]], inverse[joints["body_b"]]
+    internal = hc.expected(ob, bodies[perm], sid[perm], kind, substeps, frames, pad, joints)
+    want = np.empty_like(internal)
+    want[perm] = internal
+    assert bits_equal(got, want)
+    assert ghosts.max() < n // 3
+
+
 def test_full_size_stacks_stand_and_half_worlds_compose():
     """BASELINE configs[3] size through the contact pipeline: 262 144 stacked boxes.  The oracle is far too slow
     here, so use properties: columns stay standing, nothing goes NaN, the pair statistics are the expected ones,

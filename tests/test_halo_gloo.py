@@ -35,6 +35,31 @@ def test_sharded_oracle_run_equals_single_process(tmp_path, world_size, kind, n,
     assert bits_equal(got, want)
 
 
+def test_spatial_ordering_shrinks_halos_and_matches_the_renumbered_single_run(tmp_path):
+    """order="spatial": bodies are renumbered by grid cell before the index-range split, so each rank owns a slab of
+    space and mirrors only the bodies next to it.  The result equals the single-process run over the same renumbered
+    bodies.  (A negative `width` selects halo_common.line_scene with that pitch: a scene whose speeds respect the
+    halo margin -- the random piles of the other cases fling bodies at > 100 m/s out of their initial overlaps.)"""
+    kind, n, seed, substeps, frames, pad, pitch = capi.SCENE_BOXES_DROP, 96, 3, 8, 12, 0.02, 1.15
+    chain = dict(every=1, distance=pitch, limit=n // 2)     # links along the first row, at their rest length
+    args = (2, free_port(), str(tmp_path), "oracle", kind, n, seed, -pitch, substeps, frames, pad, 6, chain, "spatial")
+    mp.spawn(hc.worker, args=args, nprocs=2, join=True)
+    got, perm, ghosts = np.load(tmp_path / "sharded.npy"), np.load(tmp_path / "perm.npy"), np.load(tmp_path / "ghosts.npy")
+    bodies, sid = hc.line_scene(capi, kind, n, seed, pitch)
+    joints = hc.chain_joints(capi, n, **chain)
+    inverse = np.empty_like(perm)
+    inverse[perm] = np.arange(n)
+    jr = joints.copy()
+    jr["body_a"], jr["body_b"] = inverse[joints["body_a"]], inverse[joints["body_b"]]
+    want_internal = hc.expected(ob, bodies[perm], sid[perm], kind, substeps, frames, pad, jr)
+    want = np.empty_like(want_internal)
+    want[perm] = want_internal
+    assert bits_equal(got, want)
+    assert not np.array_equal(perm, np.arange(n))                    # the renumbering did happen
+    assert ghosts.max() < n // 4                                     # thin halos: a few columns, not half the world
+    assert np.abs(want[:, 22:25]).max() < 30.0                       # the scene stayed within the halo contract
+
+
 def test_halo_plan_is_conservative_and_consistent():
     rng = np.random.default_rng(1)
     n, world_size = 400, 4
