@@ -20,9 +20,22 @@ struct GjkResult {
     double point_a[3], point_b[3];
 };
 
-// One wave per pair, as launch_sat_pairs.  `out` and `manifolds` may each be NULL: manifolds receives the result as
-// a one-point Manifold (reference body A, incident body B) for the contact pipeline.
+constexpr uint32_t kEpaBlocks = 8192;   // grid of the EPA kernel (one wave per block, grid-stride over the hits)
+
+// Device scratch of the two-kernel narrowphase.  `counters`: two uint32, zero when idle; launch k appends its
+// penetrating pairs through counters[k & 1] and its EPA kernel zeroes counters[(k + 1) & 1] for the next launch
+// (all launches of one world are stream-ordered).  `pairs_scratch`: gjk_scratch_bytes(n_pairs) bytes.
+struct GjkScratch {
+    uint32_t *counters;
+    void *pairs_scratch;
+    uint32_t calls;
+};
+size_t gjk_scratch_bytes(uint32_t n_pairs);
+
+// Boolean GJK over all pairs (16 or 32 lanes per pair), then EPA over the penetrating ones (one wave per pair).
+// `out` and `manifolds` may each be NULL: manifolds receives the result as a one-point Manifold (reference body A,
+// incident body B) for the contact pipeline.
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, hipStream_t stream);
+                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, GjkScratch &scratch, hipStream_t stream);
 
 } // namespace xpbd

@@ -1,17 +1,23 @@
-// xpbd_gjk.hip -- GJK + EPA narrowphase for gfx950, one wave per body pair (extension, SURVEY 8f
-// rank 3; the reference has neither gjk nor epa -- parity UNPINNED, checker oracle/xpbd_gjk_oracle.c).
+// xpbd_gjk.hip -- GJK + EPA narrowphase for gfx950 (extension; the reference has
+// neither gjk nor epa -- parity UNPINNED, checker oracle/xpbd_gjk_oracle.c).
 //
 // Kept from the reference: the support convention of Polytope::support / minkowski_support
 // (src/geometry.rs:274-289): world-space vertex with the LAST maximal dot under f64::total_cmp, and
 // support(frame_a, d) - support(frame_b, -d) -- here with one polytope per frame.
 //
-// Mapping: both vertex sets live in LDS (world space).  A support query is one wave instruction
-// stream: lanes 0-31 evaluate A's vertices, lanes 32-63 B's, a __shfl_xor (key, index) reduction per
-// half picks the last maximum.  The GJK simplex (<= 4 points with their witnesses) stays in
-// registers, identical on every lane.  The EPA polytope (<= 52 vertices, <= 128 faces) is staged in
-// LDS: one face per lane for the closest-face search, the visibility test, the horizon test and the
-// construction of the new faces; wave prefix sums give the surviving and the new faces the same
-// canonical slots the sequential oracle uses, so the results are bit-identical.
+// Two kernels, because most broadphase pairs are separated and never need a polytope:
+//  * k_gjk_pairs<L>: the boolean GJK, L = 16 or 32 lanes per pair (4 or 2 pairs per wave).  Both vertex
+//    sets live in LDS (world space).  A support query: the first half of the group strides over A's
+//    vertices, the second half over B's, a __shfl_xor (key, index) reduction per half picks the last
+//    maximum.  The simplex (<= 4 points with their witnesses) stays in registers, identical on every
+//    lane of the group.  A pair whose simplex encloses the origin is appended to a hit list (one
+//    wave-aggregated atomic per wave) together with the vertex indices of its four simplex points.
+//  * k_epa_pairs: one wave per HIT, grid-stride over the hit list.  The polytope (<= 52 vertices,
+//    <= 128 faces) is staged in LDS: one face per lane for the closest-face search, the visibility
+//    test, the horizon test and the construction of the new faces; wave prefix sums give the
+//    surviving and the new faces the same canonical slots the sequential oracle uses.
+// Every pair's arithmetic is that of the sequential oracle, so the results are bit-identical whatever
+// the order of the hit list.
 #include <cfloat>
 #include <climits>
 
@@ -24,8 +30,11 @@ namespace {
 constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-struct GjkLds {
+struct GjkVerts {
     double wa[kMaxV][3], wb[kMaxV][3];                                        // world-space vertices
+};
+
+struct GjkLds : GjkVerts {
     double vw[kMaxEpaVerts][3], va[kMaxEpaVerts][3], vb[kMaxEpaVerts][3];      // polytope vertices + witnesses
     uint32_t fi[kMaxEpaFaces][3];                                              // faces: vertex indices (outward winding)
     double fn[kMaxEpaFaces][3];                                                //        unit normal
@@ -33,7 +42,8 @@ struct GjkLds {
 };
 
 struct MVert {
-    Vec3 w, a, b; // w = a - b
+    Vec3 w, a, b;     // w = a - b
+    uint32_t ia, ib;  // a = A's world vertex ia, b = B's world vertex ib
 };
 
 __device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
@@ -50,17 +60,26 @@ __device__ __forceinline__ long long total_key(double v)
     return i ^ (long long)((unsigned long long)(i >> 63) >> 1);
 }
 
-// support(A, d) - support(B, -d); all lanes return the same value.
-__device__ __forceinline__ MVert minkowski_support(const GjkLds &s, uint32_t na, uint32_t nb, Vec3 d, uint32_t lane)
+// support(A, d) - support(B, -d) by a group of L lanes (`lane` = lane inside the group); all lanes of the
+// group return the same value.
+template <uint32_t L>
+__device__ __forceinline__ MVert minkowski_support(const GjkVerts &s, uint32_t na, uint32_t nb, Vec3 d, uint32_t lane)
 {
-    const uint32_t half = lane >> 5, k = lane & 31u;
+    constexpr uint32_t H = L / 2;
+    const uint32_t half = lane / H, k = lane % H;
+    const uint32_t n = half ? nb : na;
+    const double(*w)[3] = half ? s.wb : s.wa;
+    const Vec3 dir = half ? -d : d;
     long long key = LLONG_MIN;
     uint32_t idx = 0;
-    if (k < (half ? nb : na)) {
-        key = total_key(half ? dot(ld3(s.wb, k), -d) : dot(ld3(s.wa, k), d));
-        idx = k;
+    for (uint32_t v = k; v < n; v += H) { // ascending v: >= keeps the LAST maximum (Iterator::max_by)
+        const long long kv = total_key(dot(ld3(w, v), dir));
+        if (kv >= key) {
+            key = kv;
+            idx = v;
+        }
     }
-    for (uint32_t off = 16; off; off >>= 1) { // maximum, HIGHEST index on ties (Iterator::max_by keeps the last)
+    for (uint32_t off = H / 2; off; off >>= 1) { // maximum, HIGHEST index on ties
         const long long ok = __shfl_xor(key, off, 64);
         const uint32_t oi = __shfl_xor(idx, off, 64);
         if (ok > key || (ok == key && oi > idx)) {
@@ -68,8 +87,9 @@ __device__ __forceinline__ MVert minkowski_support(const GjkLds &s, uint32_t na,
             idx = oi;
         }
     }
-    const Vec3 a = ld3(s.wa, __shfl(idx, 0, 64)), b = ld3(s.wb, __shfl(idx, 32, 64));
-    return MVert{a - b, a, b};
+    const uint32_t ia = __shfl(idx, 0, L), ib = __shfl(idx, H, L);
+    const Vec3 a = ld3(s.wa, ia), b = ld3(s.wb, ib);
+    return MVert{a - b, a, b, ia, ib};
 }
 
 __device__ __forceinline__ Vec3 triple(Vec3 a, Vec3 b, Vec3 c) { return cross(cross(a, b), c); }
@@ -180,118 +200,174 @@ __device__ __forceinline__ uint32_t closest_face(const GjkLds &s, uint32_t nf, u
     return bi;
 }
 
-// out: per-pair GjkResult (diagnostic entry point) and/or manifolds: one-point Manifold for the contact pipeline
-// (A = reference body, B = incident body; a degenerate query yields no contact).
-__global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
-                                                      const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                      GjkResult *__restrict__ out, Manifold *__restrict__ manifolds)
+// World-space vertices of both bodies of a pair into LDS, `group` lanes cooperating (first half A, second half B).
+__device__ __forceinline__ void stage_world_vertices(GjkVerts &s, const PolytopeTables &t, const ShapeDesc &da, const ShapeDesc &db,
+                                                     const Frame &fa, const Frame &fb, uint32_t lane, uint32_t group)
 {
-    __shared__ GjkLds s;
-    const uint32_t p = blockIdx.x, lane = threadIdx.x;
-    if (p >= n_pairs)
-        return;
-    const uint32_t ia = pairs[2 * p], ib = pairs[2 * p + 1];
+    const uint32_t H = group / 2, half = lane / H, k = lane % H;
+    const ShapeDesc dm = half ? db : da;
+    for (uint32_t vtx = k; vtx < dm.n_verts; vtx += H) {
+        const double *v = t.verts + 3 * (size_t)(dm.vert0 + vtx);
+        st3(half ? s.wb : s.wa, vtx, (half ? fb : fa) * Vec3{v[0], v[1], v[2]});
+    }
+}
+
+// Vertex indices of the four simplex points: byte k = A's index of point k, byte 4 + k = B's.
+__device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const MVert &s1, const MVert &s2, const MVert &s3)
+{
+    const unsigned long long a = s0.ia | (s1.ia << 8) | (s2.ia << 16) | (s3.ia << 24);
+    const unsigned long long b = s0.ib | (s1.ib << 8) | (s2.ib << 16) | (s3.ib << 24);
+    return a | (b << 32);
+}
+
+// Boolean GJK, L lanes per pair.  out / manifolds (each optional) receive the verdict of every pair that is NOT
+// penetrating; a penetrating pair goes to the hit list with its simplex and is finished by k_epa_pairs.
+template <uint32_t L>
+__global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+                                                  const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                  GjkResult *__restrict__ out, Manifold *__restrict__ manifolds,
+                                                  uint32_t *__restrict__ hit_count, uint32_t *__restrict__ hits,
+                                                  unsigned long long *__restrict__ seeds)
+{
+    constexpr uint32_t PW = 64 / L; // pairs per wave
+    __shared__ GjkVerts s_all[PW];
+    GjkVerts &s = s_all[threadIdx.x / L];
+    const uint32_t p = blockIdx.x * PW + threadIdx.x / L;
+    const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
+    const bool live = p < n_pairs;
+
+    uint32_t ia = 0, ib = 0, sa = 0, sb = 0;
+    ShapeDesc da{}, db{};
+    Frame fa{}, fb{};
+    if (live) {
+        ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
+        fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
+        sa = b.shape_id[ia], sb = b.shape_id[ib];
+        da = t.desc[sa], db = t.desc[sb];
+    }
+    const bool usable = live && da.n_verts != 0 && db.n_verts != 0;
+    if (usable)
+        stage_world_vertices(s, t, da, db, fa, fb, lane, L);
+    __syncthreads();
+
+    // status: 0 separated, 1 penetrating (goes to EPA), 2 degenerate; the simplex is identical on every lane of the group
+    int32_t status = 0;
+    uint32_t gjk_iters = 0;
+    MVert s0{}, s1{}, s2{}, s3{};
+    if (usable) {
+        const uint32_t na = da.n_verts, nb = db.n_verts;
+        uint32_t n = 1;
+        Vec3 d;
+        {
+            const double *ca = t.centroids + 3 * (size_t)sa, *cb = t.centroids + 3 * (size_t)sb;
+            d = fb * Vec3{cb[0], cb[1], cb[2]} - fa * Vec3{ca[0], ca[1], ca[2]};
+            if (!(dot(d, d) > 0.0))
+                d = Vec3{1.0, 0.0, 0.0};
+        }
+        s0 = minkowski_support<L>(s, na, nb, d, lane);
+        s1 = s2 = s3 = s0;
+        d = -s0.w;
+        status = 2; // running out of iterations is a degenerate query
+        for (uint32_t it = 0; it < kMaxGjkIters; ++it) {
+            gjk_iters = it + 1;
+            if (!(dot(d, d) > 0.0)) // origin on the simplex: touching / degenerate
+                break;
+            const MVert pnt = minkowski_support<L>(s, na, nb, d, lane);
+            if (!(dot(pnt.w, d) > 0.0)) { // separated (or just touching)
+                status = 0;
+                break;
+            }
+            if (n == 1) {
+                s1 = pnt;
+                n = 2;
+                const Vec3 a = s1.w, ab = s0.w - a, ao = -a;
+                if (same_dir(ab, ao)) {
+                    d = triple(ab, ao, ab);
+                } else {
+                    s0 = s1;
+                    n = 1;
+                    d = ao;
+                }
+            } else if (n == 2) {
+                const MVert A = pnt, B = s1, C = s0;
+                simplex3(A, B, C, s0, s1, s2, n, d);
+            } else {
+                const MVert A = pnt, B = s2, C = s1, D = s0;
+                const Vec3 a = A.w, ao = -a, ab = B.w - a, ac = C.w - a, ad = D.w - a;
+                const Vec3 abc = cross(ab, ac), acd = cross(ac, ad), adb = cross(ad, ab);
+                if (same_dir(abc, ao)) {
+                    simplex3(A, B, C, s0, s1, s2, n, d);
+                } else if (same_dir(acd, ao)) {
+                    simplex3(A, C, D, s0, s1, s2, n, d);
+                } else if (same_dir(adb, ao)) {
+                    simplex3(A, D, B, s0, s1, s2, n, d);
+                } else {
+                    s3 = A; // D, C, B, A enclose the origin
+                    status = 1;
+                    break;
+                }
+            }
+        }
+    }
+
+    // verdicts; the wave appends its penetrating pairs to the hit list with ONE atomic
+    const bool writer = live && lane == 0;
+    if (writer) {
+        if (out) {
+            out[p].status = status;
+            out[p].gjk_iterations = gjk_iters;
+            out[p].epa_iterations = 0;
+        }
+        if (manifolds && status != 1)
+            manifolds[p].n_points = 0;
+    }
+    const bool hit = writer && status == 1;
+    const unsigned long long hit_mask = __ballot(hit);
+    if (hit_mask) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)hit_mask) - 1u;
+        uint32_t base = 0;
+        if (threadIdx.x == leader)
+            base = atomicAdd(hit_count, (uint32_t)__popcll(hit_mask));
+        base = __shfl(base, leader, 64);
+        if (hit) {
+            const uint32_t slot = base + (uint32_t)__popcll(hit_mask & ((1ull << threadIdx.x) - 1ull));
+            hits[slot] = p;
+            seeds[p] = pack_seed(s0, s1, s2, s3);
+        }
+    }
+}
+
+// EPA of one penetrating pair by one wave; the polytope starts from the simplex k_gjk_pairs left.
+__device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
+                                         const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
+                                         GjkResult *__restrict__ out, Manifold *__restrict__ manifolds, uint32_t lane)
+{
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
-    const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
-    const ShapeDesc da = t.desc[sa], db = t.desc[sb];
+    const ShapeDesc da = t.desc[b.shape_id[ia]], db = t.desc[b.shape_id[ib]];
+    const uint32_t na = da.n_verts, nb = db.n_verts;
     GjkResult *r = out ? out + p : nullptr;
     Manifold *mf = manifolds ? manifolds + p : nullptr;
-
-    int32_t status = 0; // separated
-    uint32_t gjk_iters = 0, epa_iters = 0;
+    uint32_t epa_iters = 0;
     auto finish = [&](int32_t st) {
         if (lane == 0) {
             if (r) {
                 r->status = st;
-                r->gjk_iterations = gjk_iters;
                 r->epa_iterations = epa_iters;
             }
             if (mf && st != 1)
                 mf->n_points = 0;
         }
     };
-    if (da.n_verts == 0 || db.n_verts == 0) {
-        finish(0);
-        return;
-    }
-    {
-        const uint32_t half = lane >> 5, k = lane & 31u;
-        const ShapeDesc dm = half ? db : da;
-        if (k < dm.n_verts) {
-            const double *v = t.verts + 3 * (size_t)(dm.vert0 + k);
-            st3(half ? s.wb : s.wa, k, (half ? fb : fa) * Vec3{v[0], v[1], v[2]});
-        }
-    }
+
+    stage_world_vertices(s, t, da, db, fa, fb, lane, 64);
     __syncthreads();
-    const uint32_t na = da.n_verts, nb = db.n_verts;
-
-    // ---- boolean GJK: the simplex lives in registers, identical on every lane ----
-    MVert s0, s1, s2, s3;
-    uint32_t n = 1;
-    Vec3 d;
-    {
-        const double *ca = t.centroids + 3 * (size_t)sa, *cb = t.centroids + 3 * (size_t)sb;
-        d = fb * Vec3{cb[0], cb[1], cb[2]} - fa * Vec3{ca[0], ca[1], ca[2]};
-        if (!(dot(d, d) > 0.0))
-            d = Vec3{1.0, 0.0, 0.0};
-    }
-    s0 = minkowski_support(s, na, nb, d, lane);
-    s1 = s2 = s3 = s0;
-    d = -s0.w;
-    bool hit = false;
-    for (uint32_t it = 0; it < kMaxGjkIters; ++it) {
-        gjk_iters = it + 1;
-        if (!(dot(d, d) > 0.0)) { // origin on the simplex: touching / degenerate
-            finish(2);
-            return;
-        }
-        const MVert pnt = minkowski_support(s, na, nb, d, lane);
-        if (!(dot(pnt.w, d) > 0.0)) { // separated (or just touching)
-            finish(0);
-            return;
-        }
-        if (n == 1) {
-            s1 = pnt;
-            n = 2;
-            const Vec3 a = s1.w, ab = s0.w - a, ao = -a;
-            if (same_dir(ab, ao)) {
-                d = triple(ab, ao, ab);
-            } else {
-                s0 = s1;
-                n = 1;
-                d = ao;
-            }
-        } else if (n == 2) {
-            const MVert A = pnt, B = s1, C = s0;
-            simplex3(A, B, C, s0, s1, s2, n, d);
-        } else {
-            const MVert A = pnt, B = s2, C = s1, D = s0;
-            const Vec3 a = A.w, ao = -a, ab = B.w - a, ac = C.w - a, ad = D.w - a;
-            const Vec3 abc = cross(ab, ac), acd = cross(ac, ad), adb = cross(ad, ab);
-            if (same_dir(abc, ao)) {
-                simplex3(A, B, C, s0, s1, s2, n, d);
-            } else if (same_dir(acd, ao)) {
-                simplex3(A, C, D, s0, s1, s2, n, d);
-            } else if (same_dir(adb, ao)) {
-                simplex3(A, D, B, s0, s1, s2, n, d);
-            } else {
-                s3 = A; // D, C, B, A enclose the origin
-                hit = true;
-                break;
-            }
-        }
-    }
-    if (!hit) {
-        finish(2);
-        return;
-    }
-
-    // ---- EPA: the polytope is staged in LDS ----
     if (lane < 4) {
-        const MVert &m = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? s2 : s3));
-        st3(s.vw, lane, m.w);
-        st3(s.va, lane, m.a);
-        st3(s.vb, lane, m.b);
+        const uint32_t va = (uint32_t)(seed >> (8 * lane)) & 0xFFu, vb = (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu;
+        const Vec3 a = ld3(s.wa, va), bb = ld3(s.wb, vb);
+        st3(s.vw, lane, a - bb);
+        st3(s.va, lane, a);
+        st3(s.vb, lane, bb);
     }
     __syncthreads();
     uint32_t nv = 4, nf = 4;
@@ -317,7 +393,7 @@ __global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTabl
         double best_dist;
         const uint32_t best = closest_face(s, nf, lane, &best_dist);
         const Vec3 bn = ld3(s.fn, best);
-        const MVert pnt = minkowski_support(s, na, nb, bn, lane);
+        const MVert pnt = minkowski_support<64>(s, na, nb, bn, lane);
         if (dot(pnt.w, bn) - best_dist < kEpaTolerance || nv == kMaxEpaVerts)
             break;
 
@@ -426,18 +502,50 @@ __global__ void __launch_bounds__(64) k_gjk_epa_pairs(BodyArrays b, PolytopeTabl
             mf->p_inc[0][0] = pb.x, mf->p_inc[0][1] = pb.y, mf->p_inc[0][2] = pb.z;
         }
     }
-    (void)status;
     finish(1);
+}
+
+// One wave per block, grid-stride over the hit list of the k_gjk_pairs launch before it.  Block 0 also zeroes the
+// counter the NEXT k_gjk_pairs launch appends through (the two counters alternate, see GjkScratch).
+__global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+                                                  const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
+                                                  Manifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_count,
+                                                  uint32_t *__restrict__ next_hit_count, const uint32_t *__restrict__ hits,
+                                                  const unsigned long long *__restrict__ seeds)
+{
+    __shared__ GjkLds s;
+    const uint32_t n_hits = *hit_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *next_hit_count = 0;
+    for (uint32_t h = blockIdx.x; h < n_hits; h += gridDim.x) {
+        const uint32_t p = hits[h];
+        epa_pair(s, b, t, frames, pairs, p, seeds[p], out, manifolds, threadIdx.x);
+        __syncthreads(); // the next hit reuses the LDS
+    }
 }
 
 } // namespace
 
+size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 12 + 8; }
+
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, hipStream_t stream)
+                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, GjkScratch &scratch, hipStream_t stream)
 {
-    if (n_pairs)
-        hipLaunchKernelGGL(k_gjk_epa_pairs, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
-                           manifolds);
+    if (n_pairs == 0)
+        return hipSuccess;
+    unsigned long long *seeds = static_cast<unsigned long long *>(scratch.pairs_scratch);
+    uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + n_pairs);
+    uint32_t *count = scratch.counters + (scratch.calls & 1u), *next = scratch.counters + ((scratch.calls + 1u) & 1u);
+    ++scratch.calls;
+    if (t.lanes_per_pair <= 32) // shapes of at most 16 vertices: 16 lanes per pair, four pairs per wave
+        hipLaunchKernelGGL(k_gjk_pairs<16>, dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
+                           manifolds, count, hits, seeds);
+    else
+        hipLaunchKernelGGL(k_gjk_pairs<32>, dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
+                           manifolds, count, hits, seeds);
+    const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
+    hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, next, hits,
+                       seeds);
     return hipGetLastError();
 }
 

@@ -121,6 +121,8 @@ struct xpbd_world {
     bool have_neighbours = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
     uint32_t n_joints = 0;
+    DeviceBuffer gjk_counters, gjk_pairs_scratch;   // hit list of the two-kernel GJK/EPA narrowphase (xpbd_gjk.h)
+    xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0};
     xpbd::ContactBuffers contact_buffers() const
     {
         xpbd::ContactBuffers c{};
@@ -179,6 +181,20 @@ uint32_t next_pow2(uint32_t v)
     return p;
 }
 
+// Scratch of launch_gjk_epa_pairs for `n_pairs` pairs (growing it frees the old block, which waits for the device).
+int ensure_gjk_scratch(xpbd_world *w, uint32_t n_pairs)
+{
+    if (!w->gjk_counters.ptr) {
+        XPBD_HIP_TRY(w->gjk_counters.reserve(8));
+        XPBD_HIP_TRY(hipMemsetAsync(w->gjk_counters.ptr, 0, 8, w->stream));
+        w->gjk_scratch.calls = 0;
+    }
+    XPBD_HIP_TRY(w->gjk_pairs_scratch.reserve(xpbd::gjk_scratch_bytes(n_pairs ? n_pairs : 1)));
+    w->gjk_scratch.counters = w->gjk_counters.as<uint32_t>();
+    w->gjk_scratch.pairs_scratch = w->gjk_pairs_scratch.ptr;
+    return XPBD_OK;
+}
+
 // Sphere broadphase of the contact pipeline: neighbour lists + pair list for the coming frame.
 int build_neighbours(xpbd_world *w, double dt)
 {
@@ -232,7 +248,10 @@ int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_ro
     const xpbd::ContactBuffers c = w->contact_buffers();
     XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, trace_row, w->stream));
     if (w->narrowphase == XPBD_NARROWPHASE_GJK_EPA) {
-        XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds, w->stream));
+        if (int rc = ensure_gjk_scratch(w, w->n_pairs))
+            return rc;
+        XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds,
+                                                w->gjk_scratch, w->stream));
         XPBD_HIP_TRY(xpbd::launch_manifold_stats(c.manifolds, w->n_pairs, c.stats, w->stream));
     } else {
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
@@ -346,7 +365,8 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_key, &w->cb_maxr, &w->cb_bucket_start, &w->cb_bucket_cursor, &w->cb_items,
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
-                            &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list})
+                            &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
+                            &w->gjk_pairs_scratch})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
@@ -772,9 +792,11 @@ int xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_
     XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
     XPBD_HIP_TRY(hipMemsetAsync(w->manifold_buf.ptr, 0, (size_t)n_pairs * sizeof(xpbd::GjkResult), w->stream));
     XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
+    if (int rc = ensure_gjk_scratch(w, n_pairs))
+        return rc;
     XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(),
                                             w->pair_buf.as<uint32_t>(), n_pairs, w->manifold_buf.as<xpbd::GjkResult>(),
-                                            nullptr, w->stream));
+                                            nullptr, w->gjk_scratch, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::GjkResult), hipMemcpyDeviceToHost,
                                 w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
