@@ -26,6 +26,8 @@ struct ContactBuffers {
     uint32_t *bucket_cursor;// [table_size]
     uint32_t *items;        // [n] body ids grouped by bucket, ascending inside a bucket
     uint32_t table_size;
+    double *slot_sphere;    // [4][stride] centre xyz and radius of items[s], i.e. in bucket order
+    int32_t *slot_cell;     // [3][stride] cell of items[s]
     // neighbour lists (CSR, ascending) and the pair list i < j
     uint32_t *nbr_off;      // [n + 1]
     uint32_t *pair_first;   // [n + 1]

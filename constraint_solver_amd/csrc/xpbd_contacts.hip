@@ -19,6 +19,9 @@ namespace {
 
 constexpr uint32_t kBlock = 256;
 
+// Bucket key of a grid cell.  (Tried: a Morton interleave of the coordinates, so that neighbouring cells share cache
+// lines.  With equal bits per axis a flat scene -- 144 x 144 x 9 cells -- folds six cells onto one bucket and the
+// search slowed down, 178 -> 196 us at 262 144 stacked boxes; the multiplicative hash spreads any extent evenly.)
 __device__ __forceinline__ uint32_t cell_hash(int32_t x, int32_t y, int32_t z)
 {
     return ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349663u) ^ ((uint32_t)z * 83492791u);
@@ -119,18 +122,25 @@ __global__ void k_bounds(BodyArrays b, PolytopeTables t, const double *__restric
                          ContactBuffers c)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
-        return;
-    const uint32_t sid = b.shape_id[i];
-    const double *cc = t.centroids + 3 * (size_t)sid;
-    const Vec3 centre = body_frame(b, i) * Vec3{cc[0], cc[1], cc[2]};
-    const Vec3 vel = load3(b.dyn, D_VEL, b.stride, i);
-    const double rs = shape_radius[sid], travel = length(vel) * dt;
-    const double r = rs + (travel < rs ? travel : rs) + pad;
-    store3(c.centers, 0, b.stride, i, centre);
-    c.radius[i] = r;
-    if (r > 0.0 && r <= DBL_MAX) // positive finite doubles order like their bit patterns
-        atomicMax(c.max_radius_bits, (unsigned long long)__double_as_longlong(r));
+    double r = 0.0;
+    if (i < b.n) {
+        const uint32_t sid = b.shape_id[i];
+        const double *cc = t.centroids + 3 * (size_t)sid;
+        const Vec3 centre = body_frame(b, i) * Vec3{cc[0], cc[1], cc[2]};
+        const Vec3 vel = load3(b.dyn, D_VEL, b.stride, i);
+        const double rs = shape_radius[sid], travel = length(vel) * dt;
+        r = rs + (travel < rs ? travel : rs) + pad;
+        store3(c.centers, 0, b.stride, i, centre);
+        c.radius[i] = r;
+    }
+    // positive finite doubles order like their bit patterns; one atomic per wave (same-address atomics serialize)
+    unsigned long long bits = (r > 0.0 && r <= DBL_MAX) ? (unsigned long long)__double_as_longlong(r) : 0ull;
+    for (uint32_t off = 32; off; off >>= 1) {
+        const unsigned long long other = __shfl_xor(bits, off, 64);
+        bits = other > bits ? other : bits;
+    }
+    if ((threadIdx.x & 63u) == 0 && bits)
+        atomicMax(c.max_radius_bits, bits);
 }
 
 // Grid cell (edge = 2 * largest radius, so overlapping spheres sit in adjacent cells) and bucket count.
@@ -185,74 +195,178 @@ __global__ void k_sort_buckets(ContactBuffers c)
     }
 }
 
-// Calls visit(j) for every body j != i whose sphere overlaps body i's, each exactly once.
-template <class Visit>
-__device__ __forceinline__ void for_each_neighbour(const BodyArrays &b, const ContactBuffers &c, uint32_t i, Visit visit)
+// Bounding spheres and cells once more, in bucket (slot) order: a bucket scan then reads contiguous memory.
+__global__ void k_gather_slots(BodyArrays b, ContactBuffers c)
 {
-    const Vec3 ci = load3(c.centers, 0, b.stride, i);
-    const double ri = c.radius[i];
-    const int32_t cx = c.cell[i], cy = c.cell[(size_t)b.stride + i], cz = c.cell[(size_t)2 * b.stride + i];
-    for (int32_t dz = -1; dz <= 1; ++dz)
-        for (int32_t dy = -1; dy <= 1; ++dy)
-            for (int32_t dx = -1; dx <= 1; ++dx) {
-                const int32_t nx = cx + dx, ny = cy + dy, nz = cz + dz;
-                const uint32_t key = cell_hash(nx, ny, nz) & (c.table_size - 1);
-                const uint32_t lo = c.bucket_start[key], hi = c.bucket_start[key + 1];
-                for (uint32_t s = lo; s < hi; ++s) {
-                    const uint32_t j = c.items[s];
-                    if (j == i)
-                        continue;
-                    // several cells can share a bucket: take j only from the cell being visited
-                    if (c.cell[j] != nx || c.cell[(size_t)b.stride + j] != ny || c.cell[(size_t)2 * b.stride + j] != nz)
-                        continue;
-                    const Vec3 d = ci - load3(c.centers, 0, b.stride, j);
-                    const double reach = ri + c.radius[j];
-                    if (dot(d, d) < reach * reach)
-                        visit(j);
-                }
-            }
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= b.n)
+        return;
+    const uint32_t j = c.items[s];
+    const size_t st = b.stride;
+#pragma unroll
+    for (uint32_t a = 0; a < 3; ++a) {
+        c.slot_sphere[a * st + s] = c.centers[a * st + j];
+        c.slot_cell[a * st + s] = c.cell[a * st + j];
+    }
+    c.slot_sphere[3 * st + s] = c.radius[j];
 }
 
-__global__ void k_neighbour_count(BodyArrays b, ContactBuffers c)
+constexpr uint32_t kCellLanes = 8;    // lanes per body in the neighbour kernels
+constexpr uint32_t kNbrStage = 128;   // neighbours of one body staged in LDS for the rank sort
+constexpr uint32_t kBodiesPerBlock = kBlock / kCellLanes;
+
+// Bucket ranges of the 27 cells around one body, in LDS (one row per body of the block).
+struct CellRanges {
+    uint32_t start[kBodiesPerBlock][27];
+    uint32_t len[kBodiesPerBlock][27];
+};
+
+// Neighbour search of body i by its group of kCellLanes lanes (`cl` = lane inside the group, `g` = the group's row in
+// the LDS tables).  First the 27 bucket ranges are fetched side by side; then the lanes stride over the CONCATENATION
+// of the 27 ranges, so every lane has independent loads in flight whatever the occupancy of the single cells.
+// Several cells can share a bucket, so a candidate counts only when it sits in the cell being visited: every
+// overlapping j != i is visited exactly once, by exactly one lane.  Must be called by all lanes of the block
+// (`live` = false for the groups past the last body): it contains a barrier.
+template <class Visit>
+__device__ __forceinline__ void for_each_neighbour(const BodyArrays &b, const ContactBuffers &c, CellRanges &r, uint32_t i, bool live,
+                                                   uint32_t g, uint32_t cl, Visit visit)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
+    const size_t st = b.stride;
+    int32_t cx = 0, cy = 0, cz = 0;
+    if (live) {
+        cx = c.cell[i], cy = c.cell[st + i], cz = c.cell[2 * st + i];
+        for (uint32_t k = cl; k < 27; k += kCellLanes) {
+            const int32_t nx = cx + (int32_t)(k % 3) - 1, ny = cy + (int32_t)((k / 3) % 3) - 1, nz = cz + (int32_t)(k / 9) - 1;
+            const uint32_t key = cell_hash(nx, ny, nz) & (c.table_size - 1);
+            const uint32_t lo = c.bucket_start[key];
+            r.start[g][k] = lo;
+            r.len[g][k] = c.bucket_start[key + 1] - lo;
+        }
+    }
+    __syncthreads();
+    if (!live)
         return;
+    const Vec3 ci = load3(c.centers, 0, b.stride, i);
+    const double ri = c.radius[i];
+    uint32_t k = 0, base = 0; // cell being walked and the position of its first candidate in the concatenation
+    for (uint32_t q = cl;; q += kCellLanes) {
+        while (k < 27 && q >= base + r.len[g][k])
+            base += r.len[g][k++];
+        if (k == 27)
+            break;
+        const uint32_t s = r.start[g][k] + (q - base);
+        const int32_t nx = cx + (int32_t)(k % 3) - 1, ny = cy + (int32_t)((k / 3) % 3) - 1, nz = cz + (int32_t)(k / 9) - 1;
+        if (c.slot_cell[s] != nx || c.slot_cell[st + s] != ny || c.slot_cell[2 * st + s] != nz)
+            continue;
+        const uint32_t j = c.items[s];
+        if (j == i)
+            continue;
+        const Vec3 d = ci - load3(c.slot_sphere, 0, b.stride, s);
+        const double reach = ri + c.slot_sphere[3 * st + s];
+        if (dot(d, d) < reach * reach)
+            visit(j);
+    }
+}
+
+__device__ __forceinline__ uint32_t cell_group_sum(uint32_t v)
+{
+    for (uint32_t off = kCellLanes / 2; off; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Counts of all neighbours of every body and of those with a larger id.
+__global__ void __launch_bounds__(kBlock) k_neighbour_count(BodyArrays b, ContactBuffers c)
+{
+    __shared__ CellRanges ranges;
+    const uint32_t g = threadIdx.x / kCellLanes, cl = threadIdx.x % kCellLanes;
+    const uint32_t slot = blockIdx.x * kBodiesPerBlock + g; // bodies in bucket order: neighbours in space share lookups
+    const bool live = slot < b.n;
+    const uint32_t i = live ? c.items[slot] : 0u;
     uint32_t all = 0, upper = 0;
-    for_each_neighbour(b, c, i, [&](uint32_t j) {
+    for_each_neighbour(b, c, ranges, i, live, g, cl, [&](uint32_t j) {
         ++all;
         upper += j > i;
     });
-    c.nbr_off[i] = all;
-    c.pair_first[i] = upper;
+    if (!live)
+        return;
+    all = cell_group_sum(all);
+    upper = cell_group_sum(upper);
+    if (cl == 0) {
+        c.nbr_off[i] = all;
+        c.pair_first[i] = upper;
+    }
 }
 
-// Neighbour list of every body, ascending (insertion sort while filling; lists are short), the
-// pair list i < j in (i, j) order, and for every list entry the index of its pair.
-__global__ void k_neighbour_fill(BodyArrays b, ContactBuffers c)
+// Neighbour list of every body, ASCENDING, the pair list i < j in (i, j) order, and upper_start.  The lanes append
+// their finds to an LDS list in arrival order; a rank sort (ids are distinct) then gives every entry its final
+// place, so the result does not depend on that order.  Lists longer than kNbrStage take a one-lane path.
+__global__ void __launch_bounds__(kBlock) k_neighbour_fill(BodyArrays b, ContactBuffers c)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
-        return;
-    const uint32_t lo = c.nbr_off[i];
-    uint32_t count = 0;
-    for_each_neighbour(b, c, i, [&](uint32_t j) {
-        uint32_t p = lo + count;
-        while (p > lo && c.nbr[p - 1] > j) {
-            c.nbr[p] = c.nbr[p - 1];
-            --p;
-        }
-        c.nbr[p] = j;
-        ++count;
+    __shared__ CellRanges ranges;
+    __shared__ uint32_t stage[kBodiesPerBlock][kNbrStage];
+    __shared__ uint32_t cursor[kBodiesPerBlock];
+    const uint32_t g = threadIdx.x / kCellLanes, cl = threadIdx.x % kCellLanes;
+    const uint32_t slot = blockIdx.x * kBodiesPerBlock + g;
+    const bool live = slot < b.n;
+    const uint32_t i = live ? c.items[slot] : 0u;
+    uint32_t lo = 0, total = 0;
+    if (live) {
+        lo = c.nbr_off[i];
+        total = c.nbr_off[i + 1] - lo;
+    }
+    const bool staged = total <= kNbrStage;
+    if (cl == 0)
+        cursor[g] = 0; // for_each_neighbour's barrier comes before the first visit
+    for_each_neighbour(b, c, ranges, i, live, g, cl, [&](uint32_t j) {
+        const uint32_t pos = atomicAdd(&cursor[g], 1u);
+        if (staged)
+            stage[g][pos] = j;
+        else
+            c.nbr[lo + pos] = j;
     });
-    uint32_t below = 0;
-    while (below < count && c.nbr[lo + below] < i)
-        ++below;
-    c.upper_start[i] = lo + below;
+    __syncthreads();
+    if (!live)
+        return;
     const uint32_t first = c.pair_first[i];
-    for (uint32_t k = below; k < count; ++k) {
-        c.pairs[2 * (size_t)(first + k - below)] = i;
-        c.pairs[2 * (size_t)(first + k - below) + 1] = c.nbr[lo + k];
+    if (staged) {
+        // entry e of the arrival list goes to place rank(e); lane cl takes e = cl, cl + kCellLanes, ...
+        uint32_t below = 0;
+        for (uint32_t e = cl; e < total; e += kCellLanes)
+            below += stage[g][e] < i;
+        below = cell_group_sum(below);
+        if (cl == 0)
+            c.upper_start[i] = lo + below;
+        for (uint32_t e = cl; e < total; e += kCellLanes) {
+            const uint32_t v = stage[g][e];
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < total; ++k)
+                rank += stage[g][k] < v;
+            c.nbr[lo + rank] = v;
+            if (v > i) {
+                const size_t pair = (size_t)first + (rank - below);
+                c.pairs[2 * pair] = i;
+                c.pairs[2 * pair + 1] = v;
+            }
+        }
+    } else if (cl == 0) {
+        for (uint32_t a = lo + 1; a < lo + total; ++a) {
+            const uint32_t v = c.nbr[a];
+            uint32_t q = a;
+            while (q > lo && c.nbr[q - 1] > v) {
+                c.nbr[q] = c.nbr[q - 1];
+                --q;
+            }
+            c.nbr[q] = v;
+        }
+        uint32_t below = 0;
+        while (below < total && c.nbr[lo + below] < i)
+            ++below;
+        c.upper_start[i] = lo + below;
+        for (uint32_t k = below; k < total; ++k) {
+            c.pairs[2 * (size_t)(first + k - below)] = i;
+            c.pairs[2 * (size_t)(first + k - below) + 1] = c.nbr[lo + k];
+        }
     }
 }
 
@@ -538,13 +652,14 @@ hipError_t launch_build_buckets(const BodyArrays &b, const ContactBuffers &c, hi
         return e;
     hipLaunchKernelGGL(k_scatter, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
     hipLaunchKernelGGL(k_sort_buckets, dim3(blocks_for(c.table_size)), dim3(kBlock), 0, stream, c);
+    hipLaunchKernelGGL(k_gather_slots, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
     return hipGetLastError();
 }
 
 hipError_t launch_neighbour_count(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream)
 {
     if (b.n)
-        hipLaunchKernelGGL(k_neighbour_count, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+        hipLaunchKernelGGL(k_neighbour_count, dim3((b.n + kBodiesPerBlock - 1) / kBodiesPerBlock), dim3(kBlock), 0, stream, b, c);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = launch_exclusive_scan(c.nbr_off, b.n, c.scan_scratch, stream);
@@ -557,7 +672,7 @@ hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, h
 {
     if (b.n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_neighbour_fill, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
+    hipLaunchKernelGGL(k_neighbour_fill, dim3((b.n + kBodiesPerBlock - 1) / kBodiesPerBlock), dim3(kBlock), 0, stream, b, c);
     hipLaunchKernelGGL(k_neighbour_pair_index, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
     return hipGetLastError();
 }

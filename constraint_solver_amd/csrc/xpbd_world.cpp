@@ -116,7 +116,7 @@ struct xpbd_world {
     uint32_t narrowphase = XPBD_NARROWPHASE_SAT;
     DeviceBuffer dyn_alt, cb_centers, cb_radius, cb_cell, cb_key, cb_maxr, cb_bucket_start, cb_bucket_cursor, cb_items,
         cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_frame_p1, cb_frame_past,
-        cb_past_pos, cb_manifolds, cb_stats, cb_scan;
+        cb_past_pos, cb_manifolds, cb_stats, cb_scan, cb_slot_sphere, cb_slot_cell;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
@@ -135,6 +135,8 @@ struct xpbd_world {
         c.bucket_cursor = cb_bucket_cursor.as<uint32_t>();
         c.items = cb_items.as<uint32_t>();
         c.table_size = table_size;
+        c.slot_sphere = cb_slot_sphere.as<double>();
+        c.slot_cell = cb_slot_cell.as<int32_t>();
         c.nbr_off = cb_nbr_off.as<uint32_t>();
         c.pair_first = cb_pair_first.as<uint32_t>();
         c.upper_start = cb_upper_start.as<uint32_t>();
@@ -208,6 +210,8 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_bucket_start.reserve((size_t)(w->table_size + 1) * 4));
     XPBD_HIP_TRY(w->cb_bucket_cursor.reserve((size_t)w->table_size * 4));
     XPBD_HIP_TRY(w->cb_items.reserve((size_t)st * 4));
+    XPBD_HIP_TRY(w->cb_slot_sphere.reserve((size_t)4 * st * 8));
+    XPBD_HIP_TRY(w->cb_slot_cell.reserve((size_t)3 * st * 4));
     XPBD_HIP_TRY(w->cb_nbr_off.reserve((size_t)(st + 1) * 4));
     XPBD_HIP_TRY(w->cb_pair_first.reserve((size_t)(st + 1) * 4));
     XPBD_HIP_TRY(w->cb_upper_start.reserve((size_t)st * 4));
@@ -366,7 +370,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
-                            &w->gjk_pairs_scratch})
+                            &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);

@@ -122,8 +122,9 @@ def pile(kind, n, seed, width, height):
 
 
 @pytest.mark.parametrize("kind,n,spread", [(capi.SCENE_BOXES, 3000, 12.0), (capi.SCENE_MIXED, 2000, 6.0),
-                                           (capi.SCENE_BOXES, 70, 1.0)])
+                                           (capi.SCENE_BOXES, 70, 1.0), (capi.SCENE_MIXED, 300, 0.5)])
 def test_broadphase_matches_brute_force(kind, n, spread):
+    """(the 300-body clump gives every body 299 neighbours: the one-lane path for lists beyond the LDS stage)"""
     bodies, sid = cluster(kind, n, 5, spread)
     bodies[::7, 22:25] *= 30.0                                     # some fast bodies: radius grows with |v| dt
     with capi.World() as w:
@@ -180,6 +181,16 @@ def test_contact_pipeline_pile_matches_oracle(kind, n, width):
     assert np.array_equal(gm, wm)                                   # same ground-contact masks in every substep
     assert bits_equal(got, want)
     assert sum(s[1] for s in ws) > 100 and sum(s[2] for s in ws) > 200   # bodies really did collide
+
+
+def test_contact_pipeline_dense_clump_matches_oracle():
+    """150 boxes in one clump: neighbour lists of 149 entries (beyond the 128-entry LDS stage of the neighbour fill),
+    11 175 pairs; pair order, manifolds and the Jacobi sums must still be the oracle's."""
+    bodies, sid = cluster(capi.SCENE_BOXES, 150, 9, 0.4)
+    got, gm, gs, want, wm, ws = run_contacts(bodies, sid, capi.SCENE_BOXES, 3, 2)
+    assert ws[0][0] == 150 * 149 // 2
+    assert gs == ws and np.array_equal(gm, wm)
+    assert bits_equal(got, want)
 
 
 def test_contacts_mode_without_overlaps_equals_the_reference_path():
