@@ -537,7 +537,7 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + n_pairs);
     uint32_t *count = scratch.counters + (scratch.calls & 1u), *next = scratch.counters + ((scratch.calls + 1u) & 1u);
     ++scratch.calls;
-    if (t.lanes_per_pair <= 32) // shapes of at most 16 vertices: 16 lanes per pair, four pairs per wave
+    if (t.max_verts <= 16) // 16 lanes per pair, four pairs per wave
         hipLaunchKernelGGL(k_gjk_pairs<16>, dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
                            manifolds, count, hits, seeds);
     else

@@ -33,7 +33,7 @@ struct PolytopeTables {
     const double *edge_dirs;     // [total_dirs][3] shape-local direction v[e.1] - v[e.0] of the first edge with it
     const uint32_t *edge_dir_id; // [total_edges] shape-local index of every edge's direction
     uint32_t n_shapes;
-    uint32_t lanes_per_pair;     // 16, 32 or 64: sub-wave width of the narrowphase, by the largest shape
+    uint32_t max_verts, max_faces; // of the largest shape: the narrowphase launchers pick their sub-wave width by them
 };
 
 constexpr uint32_t kMaxManifoldPoints = 8;

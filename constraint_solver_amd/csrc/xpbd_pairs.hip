@@ -25,12 +25,24 @@ namespace xpbd {
 namespace {
 
 constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS; // 32
+#ifndef XPBD_SAT_MIN_WAVES_PER_SIMD
+#define XPBD_SAT_MIN_WAVES_PER_SIMD 4 // <= 128 VGPRs
+#endif
+#ifndef XPBD_SAT_MID_LANES
+#define XPBD_SAT_MID_LANES 32 // A/B on 65 536 mixed polyhedra: 16 lanes 5.19e8, 32 lanes 5.59e8 body-substeps/s
+#endif
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// Working set of one pair.  V = vertex capacity per body (the launcher picks the group width from the largest shape:
+// 16 lanes <=> at most 8 vertices, 32 <=> 16, 64 <=> kMaxV); PAD staggers the records of the pairs of a wave over
+// the LDS banks -- all groups read "vertex k of my pair" in the same instruction, and records that are a multiple of
+// 64 dwords apart would put those reads on the same banks (measured: SQ_LDS_BANK_CONFLICT = 86 % of the LDS cycles).
+template <uint32_t V, uint32_t PAD>
 struct PairLds {
-    double world[2][kMaxV][3]; // world-space vertices of A (0) and B (1)
-    double local[2][kMaxV][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space
-    double poly[2][16][3];     // clipping ping-pong
+    double world[2][V][3]; // world-space vertices of A (0) and B (1)
+    double local[2][V][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space
+    double poly[2][16][3]; // clipping ping-pong
+    uint32_t pad[PAD ? PAD : 1];
 };
 
 __device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
@@ -102,15 +114,20 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 // pair would idle 3/4 of its lanes).  All loops stride by the group width and all shuffles stay inside the
 // group, so both instantiations produce the same bits.  The block is ONE wave, hence __syncthreads() is a
 // wave-local fence and the sub-waves of a wave may diverge freely (one pair separated, the next one clipping).
-template <uint32_t L>
-__global__ void __launch_bounds__(64) k_sat_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
-                                                  const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                  Manifold *__restrict__ out)
+template <uint32_t L, uint32_t V>
+__global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(BodyArrays b, PolytopeTables t,
+                                                                               const double *__restrict__ frames,
+                                                                               const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                                               Manifold *__restrict__ out)
 {
     constexpr uint32_t H = L / 2;        // lanes per body in the two-sided stages
     constexpr uint32_t PW = 64 / L;      // pairs per wave
-    __shared__ PairLds s_all[PW];
-    PairLds &s = s_all[threadIdx.x / L];
+    static_assert(V == 8 || V == 16 || V == kMaxV, "vertex capacity per body");
+    // record size in dwords is a multiple of 64 for every V above: pad by 64 / PW dwords (two dwords keep 8-byte alignment)
+    using Lds = PairLds<V, PW == 1 ? 0u : 64u / PW>;
+    static_assert(sizeof(Lds) % 8 == 0, "pair records must stay 8-byte aligned");
+    __shared__ Lds s_all[PW];
+    Lds &s = s_all[threadIdx.x / L];
     const uint32_t p = blockIdx.x * PW + threadIdx.x / L;
     const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
     if (p >= n_pairs)
@@ -432,14 +449,16 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
                             uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream)
 {
     if (n_pairs) {
-        // lanes per pair by the largest shape: 16 (four pairs per wave) when every shape has <= 8 vertices and
-        // faces (boxes, tetrahedra), 32 (two pairs per wave) up to 16 vertices (icosahedra), else a whole wave
-        if (t.lanes_per_pair == 16)
-            hipLaunchKernelGGL(k_sat_pairs<16>, dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
-        else if (t.lanes_per_pair == 32)
-            hipLaunchKernelGGL(k_sat_pairs<32>, dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        // lanes per pair and vertex capacity by the largest shape: boxes and tetrahedra (<= 8 vertices and faces) run
+        // four pairs per wave with 8-vertex records; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
+        // 16-vertex records; anything larger gets a whole wave
+        if (t.max_verts <= 8 && t.max_faces <= 8)
+            hipLaunchKernelGGL((k_sat_pairs<16, 8>), dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+        else if (t.max_verts <= 16)
+            hipLaunchKernelGGL((k_sat_pairs<XPBD_SAT_MID_LANES, 16>), dim3((n_pairs + 64 / XPBD_SAT_MID_LANES - 1) / (64 / XPBD_SAT_MID_LANES)),
+                               dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         else
-            hipLaunchKernelGGL(k_sat_pairs<64>, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+            hipLaunchKernelGGL((k_sat_pairs<64, kMaxV>), dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         if (stats) {
             const uint32_t nb = (n_pairs + 255) / 256;
             hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);

@@ -102,13 +102,13 @@ struct xpbd_world {
     DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
     DeviceBuffer shape_radii, edge_dirs, edge_dir_id;
     bool has_topology = false;
-    uint32_t lanes_per_pair = 64;
+    uint32_t max_verts = 0, max_faces = 0;
     xpbd::PolytopeTables tables() const
     {
         return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
                                     shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
                                     face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(),
-                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, lanes_per_pair};
+                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, max_verts, max_faces};
     }
 
     // extension: contact pipeline (XPBD_MODE_CONTACTS)
@@ -519,7 +519,8 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
         max_verts = shapes[k].n_vertices > max_verts ? shapes[k].n_vertices : max_verts;
         max_faces = shapes[k].n_faces > max_faces ? shapes[k].n_faces : max_faces;
     }
-    w->lanes_per_pair = (max_verts <= 8 && max_faces <= 8) ? 16u : (max_verts <= 16 ? 32u : 64u);
+    w->max_verts = max_verts;
+    w->max_faces = max_faces;
     return XPBD_OK;
 }
 
