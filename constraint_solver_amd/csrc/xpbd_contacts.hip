@@ -18,6 +18,9 @@ namespace xpbd {
 namespace {
 
 constexpr uint32_t kBlock = 256;
+#ifndef XPBD_PAIR_SOLVE_MIN_WAVES
+#define XPBD_PAIR_SOLVE_MIN_WAVES 2
+#endif
 
 // Bucket key of a grid cell.  (Tried: a Morton interleave of the coordinates, so that neighbouring cells share cache
 // lines.  With equal bits per axis a flat scene -- 144 x 144 x 9 cells -- folds six cells onto one bucket and the
@@ -503,7 +506,7 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
     return p.inv_mass + dot(p.inv_inertia * angular_impulse, angular_impulse);
 }
 
-__global__ void __launch_bounds__(kBlock) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
+__global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
                                                               ContactBuffers c)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,30 +526,33 @@ __global__ void __launch_bounds__(kBlock) k_pair_solve_derive(BodyArrays b, doub
             continue;
         const uint32_t j = c.nbr[k];
         const PairBody other = load_pair_body(b, c, j);
-        // pair (A, B) = (min, max); the reference body is A unless the reference face is on B
+        // pair (A, B) = (min, max); the reference body is A unless the reference face is on B.  The formulas are
+        // written in terms of the incident and the reference body; here every term is evaluated for `self` and
+        // `other` with their own point and only 3-vectors are selected by role -- selecting whole bodies by a
+        // per-lane condition made the compiler keep four body records live (255 VGPRs + AGPRs, one wave per SIMD).
         const bool self_is_a = i < j;
         const bool ref_is_a = m->feature != 1u;
         const bool self_is_inc = self_is_a != ref_is_a;
-        const PairBody &inc = self_is_inc ? self : other;
-        const PairBody &ref = self_is_inc ? other : self;
         for (uint32_t pt = 0; pt < n_points; ++pt) {
             const Vec3 p_inc{m->p_inc[pt][0], m->p_inc[pt][1], m->p_inc[pt][2]};
             const Vec3 p_ref{m->p_ref[pt][0], m->p_ref[pt][1], m->p_ref[pt][2]};
+            const Vec3 p_self = self_is_inc ? p_inc : p_ref, p_other = self_is_inc ? p_ref : p_inc;
             const Vec3 correction = p_ref - p_inc;
-            const Vec3 delta_rel = frame_delta(inc.p1, inc.past, p_inc) - frame_delta(ref.p1, ref.past, p_ref);
+            const Vec3 moved_self = frame_delta(self.p1, self.past, p_self), moved_other = frame_delta(other.p1, other.past, p_other);
+            const Vec3 delta_rel = self_is_inc ? moved_self - moved_other : moved_other - moved_self; // incident - reference
             const Vec3 delta_tangential = delta_rel - project_on(delta_rel, correction);
             const Vec3 c0 = p_inc;
             const Vec3 c1 = p_ref - 1.0 * delta_tangential;
             const Vec3 difference = c1 - c0;
             const double dist = length(difference);
             const Vec3 dir = difference * (1.0 / dist);
-            const double w = generalized_inverse_mass(inc, c0, dir) + generalized_inverse_mass(ref, p_ref, dir);
+            // w = w_incident + w_reference; IEEE addition commutes, so the order of the two bodies does not matter
+            const double w = generalized_inverse_mass(self, p_self, dir) + generalized_inverse_mass(other, p_other, dir);
             const double lambda = (dist - 0.0) / (w + compliance);
 
-            const Vec3 point = self_is_inc ? c0 : p_ref;
             const Vec3 impulse = self_is_inc ? lambda * dir : (-lambda) * dir;
             dpos = dpos + impulse * self.inv_mass;
-            const Vec3 arm = point - (self.pos + self.com);
+            const Vec3 arm = p_self - (self.pos + self.com);
             const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
             drot = drot + (0.5 * spin) * self.rot;
             ++count;
@@ -559,21 +565,21 @@ __global__ void __launch_bounds__(kBlock) k_pair_solve_derive(BodyArrays b, doub
             const Joint &jt = c.joints[c.joint_list[k]];
             const bool self_is_a = jt.body_a == i;
             const PairBody other = load_pair_body(b, c, self_is_a ? jt.body_b : jt.body_a);
-            const PairBody &ja = self_is_a ? self : other;
-            const PairBody &jb = self_is_a ? other : self;
-            const Vec3 p_a = Frame{frame_origin(ja.pos, ja.rot, ja.com), ja.rot} * Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]};
-            const Vec3 p_b = Frame{frame_origin(jb.pos, jb.rot, jb.com), jb.rot} * Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]};
-            const Vec3 difference = p_b - p_a;
+            // as above: evaluate per body, select 3-vectors by role (a / b)
+            const Vec3 anchor_self = self_is_a ? Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]} : Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]};
+            const Vec3 anchor_other = self_is_a ? Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]} : Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]};
+            const Vec3 p_self = Frame{frame_origin(self.pos, self.rot, self.com), self.rot} * anchor_self;
+            const Vec3 p_other = Frame{frame_origin(other.pos, other.rot, other.com), other.rot} * anchor_other;
+            const Vec3 difference = self_is_a ? p_other - p_self : p_self - p_other; // p_b - p_a
             const double dist = length(difference);
             if (dist == 0.0)
                 continue; // coincident points: the reference's direction() would be NaN (K6); nothing to correct
             const Vec3 dir = difference * (1.0 / dist);
-            const double w = generalized_inverse_mass(ja, p_a, dir) + generalized_inverse_mass(jb, p_b, dir);
+            const double w = generalized_inverse_mass(self, p_self, dir) + generalized_inverse_mass(other, p_other, dir);
             const double lambda = (dist - jt.distance) / (w + compliance);
-            const Vec3 point = self_is_a ? p_a : p_b;
             const Vec3 impulse = self_is_a ? lambda * dir : (-lambda) * dir;
             dpos = dpos + impulse * self.inv_mass;
-            const Vec3 arm = point - (self.pos + self.com);
+            const Vec3 arm = p_self - (self.pos + self.com);
             const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
             drot = drot + (0.5 * spin) * self.rot;
             ++count;
