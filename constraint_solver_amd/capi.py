@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
+    "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
 
 
@@ -133,6 +134,11 @@ def hip_lib():
         L.xpbd_world_contacts_substep.argtypes = [C.c_void_p, C.c_double]
         L.xpbd_world_export_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.xpbd_world_import_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_history_push.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.xpbd_world_history_restore.argtypes = [C.c_void_p, C.c_uint32]
+        L.xpbd_world_history_truncate.argtypes = [C.c_void_p, C.c_uint32]
+        L.xpbd_world_history_length.argtypes = [C.c_void_p]
+        L.xpbd_world_history_length.restype = C.c_uint32
         _hip = L
     return _hip
 
@@ -310,6 +316,21 @@ class World:
 
     def import_dynamic(self, dev_indices_ptr, n, dev_buf_ptr):
         _check(hip_lib().xpbd_world_import_dynamic(self._h, C.c_void_p(dev_indices_ptr), n, C.c_void_p(dev_buf_ptr)))
+
+    # state history: the reference app's `states` vector and `current_state` cursor (src/app.rs:48, 206-212)
+    def history_push(self):
+        index = C.c_uint32(0)
+        _check(hip_lib().xpbd_world_history_push(self._h, C.byref(index)))
+        return index.value
+
+    def history_restore(self, index):
+        _check(hip_lib().xpbd_world_history_restore(self._h, index))
+
+    def history_truncate(self, length):
+        _check(hip_lib().xpbd_world_history_truncate(self._h, length))
+
+    def history_length(self):
+        return hip_lib().xpbd_world_history_length(self._h)
 
     def set_stream(self, stream_ptr):
         _check(hip_lib().xpbd_world_set_stream(self._h, C.c_void_p(stream_ptr)))

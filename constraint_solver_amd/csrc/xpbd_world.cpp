@@ -121,6 +121,11 @@ struct xpbd_world {
     bool have_neighbours = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
     uint32_t n_joints = 0;
+    // state history (xpbd_world_history_*): `history_length` slots of history_slot_bytes() in one growing block
+    DeviceBuffer history;
+    uint32_t history_length = 0;
+    std::vector<uint8_t> history_stepped;
+    size_t history_slot_bytes() const { return ((size_t)xpbd::kDynFields * stride * 8 + (size_t)stride * 4 + 255) / 256 * 256; }
     DeviceBuffer gjk_counters, gjk_pairs_scratch;   // hit list of the two-kernel GJK/EPA narrowphase (xpbd_gjk.h)
     xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0};
     xpbd::ContactBuffers contact_buffers() const
@@ -370,7 +375,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
-                            &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell})
+                            &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
@@ -572,6 +577,8 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     XPBD_HIP_TRY(w->dyn_alt.reserve((size_t)xpbd::kDynFields * stride * 8));
     w->have_neighbours = false;
     w->n_joints = 0; // joints name bodies by index: a new upload invalidates them
+    w->history_length = 0;
+    w->history_stepped.clear();
     XPBD_HIP_TRY(w->stat.reserve((size_t)xpbd::kStatFields * stride * 8));
     XPBD_HIP_TRY(w->shape_id.reserve((size_t)stride * 4));
     XPBD_HIP_TRY(w->last_mask.reserve((size_t)stride * 4));
@@ -957,6 +964,73 @@ int xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *n
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     return XPBD_OK;
 }
+
+int xpbd_world_history_push(xpbd_world *w, uint32_t *index_out)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_history_push: NULL world");
+    if (w->n == 0)
+        return fail(XPBD_E_INVALID, "xpbd_world_history_push: no bodies uploaded");
+    if (int rc = bind_device(w))
+        return rc;
+    const size_t slot = w->history_slot_bytes();
+    if ((size_t)(w->history_length + 1) * slot > w->history.bytes) {
+        // grow geometrically into a new block, carrying the old states over (device to device)
+        uint32_t capacity = (uint32_t)(w->history.bytes / slot);
+        capacity = capacity < 8 ? 8 : capacity * 2;
+        DeviceBuffer bigger;
+        hipError_t e = bigger.reserve((size_t)capacity * slot);
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? XPBD_E_OOM : XPBD_E_HIP, "xpbd_world_history_push: %u states of %zu bytes: %s",
+                        capacity, slot, hipGetErrorString(e));
+        XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+        if (w->history_length)
+            XPBD_HIP_TRY(hipMemcpy(bigger.ptr, w->history.ptr, (size_t)w->history_length * slot, hipMemcpyDeviceToDevice));
+        w->history.release();
+        w->history = bigger;
+    }
+    char *dst = static_cast<char *>(w->history.ptr) + (size_t)w->history_length * slot;
+    const size_t dyn_bytes = (size_t)xpbd::kDynFields * w->stride * 8;
+    XPBD_HIP_TRY(hipMemcpyAsync(dst, w->dyn.ptr, dyn_bytes, hipMemcpyDeviceToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(dst + dyn_bytes, w->last_mask.ptr, (size_t)w->stride * 4, hipMemcpyDeviceToDevice, w->stream));
+    w->history_stepped.push_back(w->stepped ? 1 : 0);
+    if (index_out)
+        *index_out = w->history_length;
+    ++w->history_length;
+    return XPBD_OK;
+}
+
+int xpbd_world_history_restore(xpbd_world *w, uint32_t index)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_history_restore: NULL world");
+    if (index >= w->history_length)
+        return fail(XPBD_E_INVALID, "xpbd_world_history_restore: state %u of %u", index, w->history_length);
+    if (int rc = bind_device(w))
+        return rc;
+    const size_t slot = w->history_slot_bytes();
+    const char *src = static_cast<const char *>(w->history.ptr) + (size_t)index * slot;
+    const size_t dyn_bytes = (size_t)xpbd::kDynFields * w->stride * 8;
+    XPBD_HIP_TRY(hipMemcpyAsync(w->dyn.ptr, src, dyn_bytes, hipMemcpyDeviceToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->last_mask.ptr, src + dyn_bytes, (size_t)w->stride * 4, hipMemcpyDeviceToDevice, w->stream));
+    w->stepped = w->history_stepped[index] != 0;
+    w->have_neighbours = false;
+    w->trace_rows = 0; // the per-substep trace belongs to the step call that was overwritten
+    return XPBD_OK;
+}
+
+int xpbd_world_history_truncate(xpbd_world *w, uint32_t length)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_history_truncate: NULL world");
+    if (length > w->history_length)
+        return fail(XPBD_E_INVALID, "xpbd_world_history_truncate: length %u > %u", length, w->history_length);
+    w->history_length = length;
+    w->history_stepped.resize(length);
+    return XPBD_OK;
+}
+
+uint32_t xpbd_world_history_length(const xpbd_world *w) { return w ? w->history_length : 0; }
 
 int xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b, double *quotient, double *root,
                            uint32_t n)

@@ -147,6 +147,11 @@ extern "C" {
     pub fn xpbd_world_contacts_substep(w: *mut XpbdWorld, h: f64) -> c_int;
     pub fn xpbd_world_export_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *mut f64) -> c_int;
     pub fn xpbd_world_import_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *const f64) -> c_int;
+    // state history: replaces `states: Vec<(World, DebugLines)>` of src/app.rs:48 (see HistoryWorld below)
+    pub fn xpbd_world_history_push(w: *mut XpbdWorld, index_out: *mut u32) -> c_int;
+    pub fn xpbd_world_history_restore(w: *mut XpbdWorld, index: u32) -> c_int;
+    pub fn xpbd_world_history_truncate(w: *mut XpbdWorld, length: u32) -> c_int;
+    pub fn xpbd_world_history_length(w: *const XpbdWorld) -> u32;
 }
 
 fn v3(v: Vector3<f64>) -> [f64; 3] {
@@ -242,6 +247,40 @@ impl GpuWorld {
         for (c, r) in self.staging.iter().zip(bodies.iter_mut()) {
             c.store_into(r);
         }
+    }
+}
+
+/// The app's state history (src/app.rs:48, 206-212) on the device: `states` becomes the world's history,
+/// `current_state` stays a host-side cursor.  `advance` is the body of the `RedrawRequested` loop.
+pub struct Timeline {
+    pub world: GpuWorld,
+    pub current_state: u32,
+}
+
+impl Timeline {
+    /// `states = vec![(World::new(..), ..)]; current_state = 0`
+    pub fn new(world: GpuWorld) -> Timeline {
+        check(unsafe { xpbd_world_history_push(world.handle, std::ptr::null_mut()) });
+        Timeline { world, current_state: 0 }
+    }
+
+    /// `for _ in 0..time_speed() { if current_state + 1 >= states.len() { integrate; push } current_state += 1 }`
+    pub fn advance(&mut self, dt: f64, substeps: u32, time_speed: u32) {
+        for _ in 0..time_speed {
+            let len = unsafe { xpbd_world_history_length(self.world.handle) };
+            if self.current_state + 1 >= len {
+                check(unsafe { xpbd_world_history_restore(self.world.handle, len - 1) });
+                self.world.integrate(dt, substeps);
+                check(unsafe { xpbd_world_history_push(self.world.handle, std::ptr::null_mut()) });
+            }
+            self.current_state += 1;
+        }
+    }
+
+    /// Scrubbing: show state `index` (the renderer then calls `world.read_back`).
+    pub fn seek(&mut self, index: u32) {
+        check(unsafe { xpbd_world_history_restore(self.world.handle, index) });
+        self.current_state = index;
     }
 }
 

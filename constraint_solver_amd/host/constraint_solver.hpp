@@ -481,6 +481,17 @@ class BatchWorld {
         bodies.resize(xpbd_world_body_count(w_));
         check(xpbd_world_download_bodies(w_, bodies.empty() ? nullptr : bodies[0].c(), (uint32_t)bodies.size()));
     }
+    // state history on the device (the reference app's `states` vector, src/app.rs:48)
+    uint32_t history_push()
+    {
+        uint32_t index = 0;
+        check(xpbd_world_history_push(w_, &index));
+        return index;
+    }
+    void history_restore(uint32_t index) { check(xpbd_world_history_restore(w_, index)); }
+    void history_truncate(uint32_t length) { check(xpbd_world_history_truncate(w_, length)); }
+    uint32_t history_length() const { return xpbd_world_history_length(w_); }
+
     std::vector<xpbd_contact> contacts()
     {
         uint32_t n = 0;
@@ -496,6 +507,37 @@ class BatchWorld {
 
   private:
     xpbd_world *w_ = nullptr;
+};
+
+// The reference app's state history (src/app.rs:48, 206-212): `states` lives on the device as the world's history,
+// `current_state` is the host-side cursor; advance() is the body of the RedrawRequested loop.
+class Timeline {
+  public:
+    explicit Timeline(BatchWorld &world) : world_(world) { resident_ = world_.history_push(); } // states = vec![World::new(..)]
+    void advance(double dt, uint32_t substeps, uint32_t time_speed = 1)
+    {
+        for (uint32_t k = 0; k < time_speed; ++k) {
+            const uint32_t len = world_.history_length();
+            if (current_state + 1 >= len) {
+                if (resident_ != len - 1)
+                    world_.history_restore(len - 1); // `let mut world = states[current_state].0` (the newest one here)
+                world_.integrate(dt, substeps);
+                resident_ = world_.history_push();
+            }
+            ++current_state;
+        }
+    }
+    // scrubbing: make state `index` the current one (read it back with BatchWorld::download / frames)
+    void seek(uint32_t index)
+    {
+        world_.history_restore(index);
+        current_state = resident_ = index;
+    }
+    uint32_t current_state = 0;
+
+  private:
+    BatchWorld &world_;
+    uint32_t resident_ = 0; // which state the device currently holds
 };
 
 } // namespace world

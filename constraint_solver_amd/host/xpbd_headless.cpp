@@ -4,6 +4,9 @@
 //
 //   xpbd_headless --bodies 262144 --substeps 20 --frames 10 [--scene boxes|mixed|boxes-drop|mixed-drop|stacks]
 //                 [--seed 1] [--mode fused|substep|contacts] [--device 0] [--dump poses.bin]
+//                 [--history] [--rewind K]
+// --history keeps every frame on the device like the reference app's `states` vector (src/app.rs:48) and steps through
+// world::Timeline; --rewind K then scrubs back to state K (0 = the initial world) before the dump.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +20,8 @@ using namespace constraint_solver;
 int main(int argc, char **argv)
 {
     uint32_t bodies = 4096, substeps = 20, frames = 10, warmup = 2;
+    bool history = false;
+    long rewind = -1;
     uint64_t seed = 1;
     int device = 0;
     scene::Kind kind = scene::BOXES;
@@ -41,6 +46,8 @@ int main(int argc, char **argv)
         else if (const char *v = val("--scene")) kind = std::strcmp(v, "mixed") == 0 ? scene::MIXED : std::strcmp(v, "boxes-drop") == 0 ? scene::BOXES_DROP : std::strcmp(v, "mixed-drop") == 0 ? scene::MIXED_DROP : std::strcmp(v, "stacks") == 0 ? scene::BOX_STACKS : scene::BOXES;
         else if (const char *v = val("--mode")) mode = std::strcmp(v, "substep") == 0 ? XPBD_MODE_PER_SUBSTEP : std::strcmp(v, "contacts") == 0 ? XPBD_MODE_CONTACTS : XPBD_MODE_FUSED;
         else if (const char *v = val("--dump")) dump = v;
+        else if (const char *v = val("--rewind")) rewind = std::strtol(v, nullptr, 10);
+        else if (std::strcmp(argv[i], "--history") == 0) history = true;
         else {
             std::fprintf(stderr, "unknown argument %s\n", argv[i]);
             return 2;
@@ -63,14 +70,23 @@ int main(int argc, char **argv)
         w.upload(state, shape_id);
 
         const double dt = 1.0 / 60.0; // FRAME_TIME, src/app.rs:15
+        if (history)
+            warmup = 0; // state 0 of the timeline is the initial world
         for (uint32_t f = 0; f < warmup; ++f)
             w.integrate(dt, substeps);
         w.synchronize();
+        world::Timeline timeline(w); // pushes the current state as state 0 (only used with --history)
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t f = 0; f < frames; ++f)
-            w.integrate(dt, substeps);
+        for (uint32_t f = 0; f < frames; ++f) {
+            if (history)
+                timeline.advance(dt, substeps);
+            else
+                w.integrate(dt, substeps);
+        }
         w.synchronize();
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (history && rewind >= 0)
+            timeline.seek((uint32_t)rewind);
         const double rate = (double)bodies * substeps * frames / sec;
         w.download(state);
         const auto contacts = w.contacts();

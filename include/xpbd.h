@@ -253,6 +253,22 @@ int  xpbd_world_contacts_substep(xpbd_world *w, double h);
 int  xpbd_world_export_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_buf);
 int  xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_buf);
 
+/* State history: the device-side counterpart of the reference app's `states: Vec<(World,
+ * DebugLines)>` with its `current_state` cursor (src/app.rs:48, 206-212), which lets the user
+ * scrub back through every simulated frame.  `World` is `Copy` there; here a state is the 13
+ * dynamic doubles per body plus the contact masks of the last substep, copied device-to-device
+ * (27 MB per state at 262 144 bodies -- thousands of frames fit in HBM).
+ *   push     appends the current state, *index_out (optional) = its index (= length before the call)
+ *   restore  makes state `index` the current one (neighbour lists of XPBD_MODE_CONTACTS are rebuilt
+ *            by the next step / contacts_begin); stepping on from it reproduces the original run
+ *            bit for bit
+ *   truncate drops the states with index >= length (branching off a past state)
+ * xpbd_world_upload_bodies clears the history. */
+int  xpbd_world_history_push(xpbd_world *w, uint32_t *index_out);
+int  xpbd_world_history_restore(xpbd_world *w, uint32_t index);
+int  xpbd_world_history_truncate(xpbd_world *w, uint32_t length);
+uint32_t xpbd_world_history_length(const xpbd_world *w);
+
 /* Diagnostics: quotient[i] = a[i] / b[i], root[i] = sqrt(a[i]) computed on the
  * device with the stepper's own code generation.  Bit-exact contact lists need
  * both to be correctly rounded; the parity tests check this against the host. */
