@@ -93,22 +93,18 @@ __device__ __forceinline__ SubstepFrames integrate_body(BodyDynamic &d, const Bo
     return f;
 }
 
-// collision::ground + solver::solve for one body (src/collision.rs:13-35, src/solver.rs:19-27).
-// Returns the contact mask (bit v set <=> shape vertex v produced a constraint).
+// collision::ground + solver::solve for one body (src/collision.rs:13-35, src/solver.rs:19-27), in two passes.
 //
 // ground() only reads the post-integrate pose and the past frame, and solve() consumes the
 // constraints in push order, so no constraint list is stored: constraint v is rebuilt from the
-// frozen post-integrate frame `f.cur` and immediately projected onto the live pose (pos, rot).
+// frozen post-integrate frame `cur` and immediately projected onto the live pose (pos, rot).
 // The arithmetic and its order per constraint are exactly the reference's.
-__device__ __forceinline__ uint32_t solve_ground(BodyDynamic &d, const BodyStatic &s, const SubstepFrames &f,
-                                                 double compliance, const double *verts, uint32_t n_verts)
-{
-    const Frame cur = f.cur;
-    const Frame cur_inv = inverse(cur); // src/frame.rs:30-37, shared by every penetrating vertex
 
-    // Pass 1 -- the `position.z >= 0.0` test of every vertex (src/collision.rs:17-18).  Only the
-    // z component of frame * vertex is live here, so the compiler drops the x/y arithmetic.
-    // (A NaN height fails `>=` and therefore IS a contact, as in the reference.)
+// Pass 1 -- the `position.z >= 0.0` test of every vertex (src/collision.rs:17-18): bit v set <=> shape vertex v
+// produces a constraint.  Only the z component of frame * vertex is live here, so the compiler drops the x/y
+// arithmetic.  (A NaN height fails `>=` and therefore IS a contact, as in the reference.)
+__device__ __forceinline__ uint32_t ground_mask(const Frame &cur, const double *verts, uint32_t n_verts)
+{
     uint32_t mask = 0;
     for (uint32_t v = 0; v < n_verts; ++v) {
         const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
@@ -116,12 +112,18 @@ __device__ __forceinline__ uint32_t solve_ground(BodyDynamic &d, const BodyStati
         if (!(x.z >= 0.0))
             mask |= 1u << v;
     }
+    return mask;
+}
 
-    // Pass 2 -- each lane walks ITS OWN penetrating vertices in ascending index order (the
-    // reference's push order).  Lane-compacting the contact work this way makes a wave run the
-    // expensive body max-over-lanes(contact count) times instead of once per shape vertex with
-    // most lanes masked off (resting boxes: ~4 instead of 8 trips, at twice the lane utilisation).
-    // Recomputing x for the chosen vertex repeats the pass-1 arithmetic exactly, so the bits match.
+// Pass 2 -- the lane walks the penetrating vertices of `mask` in ascending index order (the reference's push
+// order).  Lane-compacting the contact work this way makes a wave run the expensive body max-over-lanes(contact
+// count) times instead of once per shape vertex with most lanes masked off.  Recomputing x for the chosen vertex
+// repeats the pass-1 arithmetic exactly, so the bits match.  (pos, rot) is the live pose the impulses act on.
+__device__ __forceinline__ void solve_masked(Vec3 &pos, Quat &rot, double inv_mass, const Mat3 &inv_inertia, const Vec3 &com,
+                                             const Frame &cur, const Frame &past, double compliance, const double *verts,
+                                             uint32_t mask)
+{
+    const Frame cur_inv = inverse(cur); // src/frame.rs:30-37, shared by every penetrating vertex
     for (uint32_t todo = mask; todo != 0; todo &= todo - 1) {
         const uint32_t v = __ffs(todo) - 1;
         const Vec3 vertex{verts[3 * v + 0], verts[3 * v + 1], verts[3 * v + 2]};
@@ -130,8 +132,8 @@ __device__ __forceinline__ uint32_t solve_ground(BodyDynamic &d, const BodyStati
         // src/collision.rs:22-29
         const Vec3 target{x.x, x.y, 0.0};
         const Vec3 correction = target - x;
-        const Vec3 local = cur_inv * x;        // src/frame.rs:41
-        const Vec3 delta = x - f.past * local; // src/frame.rs:42-43
+        const Vec3 local = cur_inv * x;      // src/frame.rs:41
+        const Vec3 delta = x - past * local; // src/frame.rs:42-43
         const Vec3 delta_tangential = delta - project_on(delta, correction);
         const Vec3 c0 = x;
         const Vec3 c1 = target - 1.0 * delta_tangential;
@@ -141,17 +143,25 @@ __device__ __forceinline__ uint32_t solve_ground(BodyDynamic &d, const BodyStati
         const double current_distance = length(difference);           // src/constraint.rs:21-23
         const Vec3 direction = difference * (1.0 / current_distance); // src/constraint.rs:17-19
         // inverse_resitance, src/constraint.rs:25-32 (reads the LIVE pose)
-        const Vec3 angular_impulse = conjugate(d.rot) * cross(c0 - (d.pos + s.com), direction);
-        const double w = s.inv_mass + dot(s.inv_inertia * angular_impulse, angular_impulse);
+        const Vec3 angular_impulse = conjugate(rot) * cross(c0 - (pos + com), direction);
+        const double w = inv_mass + dot(inv_inertia * angular_impulse, angular_impulse);
         const double lagrange = (current_distance - 0.0) / (w + compliance);
         // act -> apply_impulse, src/constraint.rs:34-37, src/rigid.rs:113-123
         const Vec3 impulse = lagrange * direction;
-        d.pos = d.pos + impulse * s.inv_mass;
-        const Vec3 arm = c0 - (d.pos + s.com);
-        const Quat spin = quat_sv(0.0, cross(s.inv_inertia * arm, impulse));
-        d.rot = d.rot + (0.5 * spin) * d.rot;
-        d.rot = normalized(d.rot);
+        pos = pos + impulse * inv_mass;
+        const Vec3 arm = c0 - (pos + com);
+        const Quat spin = quat_sv(0.0, cross(inv_inertia * arm, impulse));
+        rot = rot + (0.5 * spin) * rot;
+        rot = normalized(rot);
     }
+}
+
+// Both passes for the lane's own body.  Returns the contact mask.
+__device__ __forceinline__ uint32_t solve_ground(BodyDynamic &d, const BodyStatic &s, const SubstepFrames &f,
+                                                 double compliance, const double *verts, uint32_t n_verts)
+{
+    const uint32_t mask = ground_mask(f.cur, verts, n_verts);
+    solve_masked(d.pos, d.rot, s.inv_mass, s.inv_inertia, s.com, f.cur, f.past, compliance, verts, mask);
     return mask;
 }
 

@@ -201,7 +201,11 @@ class ShardedContactWorld:
         self.ghost_idx = b.index_tensor(ghost_slots)
         self.ghost_rows = b.torch.as_tensor(rows, device=self.boundary_idx.device)
         self.send = b.empty(self.plan.capacity)
+        self.recv = b.empty(self.plan.capacity * self.world_size)
         self.n_boundary = len(boundary_slots)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            self._on_gloo = dist.get_backend(self.group) == "gloo"
 
     def _exchange(self):
         if self.world_size == 1:
@@ -210,14 +214,16 @@ class ShardedContactWorld:
         b = self.backend
         if self.n_boundary:
             b.export(self.boundary_idx, self.send[: self.n_boundary])
-        on_gloo = dist.get_backend(self.group) == "gloo"
-        send = self.send.cpu() if (on_gloo and self.send.is_cuda) else self.send
-        parts = [send.new_empty(send.shape) for _ in range(self.world_size)]
-        dist.all_gather(parts, send, group=self.group)               # halo all-gather (RCCL when nccl)
-        gathered = b.torch.cat(parts, dim=0)
+        # ONE collective per substep into a buffer allocated at plan time (RCCL over xGMI when the backend is nccl;
+        # the collective is ordered after the export kernel and before the import kernel on the world's stream)
+        if self._on_gloo and self.send.is_cuda:                      # single-GPU rehearsal: gloo moves host memory
+            host = self.recv.cpu()
+            dist.all_gather_into_tensor(host, self.send.cpu(), group=self.group)
+            self.recv.copy_(host)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         if len(self.ghost_rows):
-            recv = gathered[self.ghost_rows.to(gathered.device)]
-            b.import_(self.ghost_idx, recv.to(self.send.device))
+            b.import_(self.ghost_idx, self.recv[self.ghost_rows])
 
     def step(self, dt, substeps):
         """xpbd_world_step(dt, substeps) of the whole sharded world (lock step over ranks)."""
