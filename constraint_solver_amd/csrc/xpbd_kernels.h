@@ -52,9 +52,6 @@ constexpr uint32_t kBytesPerBodySubstep = (13 + 25) * 8 + 4 + 13 * 8; // 412
 // last_mask[i]      <- contact mask of the final substep (always written).
 // trace_masks       <- optional [substeps][stride_trace] masks of every substep,
 //                      written starting at row `trace_row0`.
-// The same substeps with the contact work of each 256-body workgroup regrouped by contact count (bit-identical results).
-hipError_t launch_step_regroup(const BodyArrays &b, const ShapeTable &s, double h, uint32_t substeps, uint32_t *last_mask,
-                               uint32_t *trace_masks, uint32_t trace_row0, hipStream_t stream);
 hipError_t launch_step(const BodyArrays &b, const ShapeTable &s, double h, uint32_t substeps,
                        uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row0,
                        uint32_t block_size, hipStream_t stream);

@@ -69,143 +69,6 @@ __global__ void __launch_bounds__(kMaxStepBlock, XPBD_STEP_MIN_WAVES_PER_SIMD) k
 }
 
 // ---------------------------------------------------------------------------
-// k_step_regroup: k_step with the contact work of a workgroup REGROUPED in every substep.
-//
-// In k_step a wave runs pass 2 (build + project one ground constraint, ~380 instructions) max-over-its-lanes of the
-// contact count times: on the benchmark scene 3.75 trips where 1.68 are useful.  Bodies are independent, so any
-// lane may project any body's constraints: after pass 1 the 256 bodies of the workgroup are ranked by contact
-// count (counting sort over the keys 8+ .. 1), every body with contacts parks what pass 2 needs in LDS at its rank
-// (pose, past frame, inverse mass and inertia, centre of mass, mask, shape: 27 doubles + 2 words), lane t adopts
-// the body of rank t, projects its constraints and writes the pose back; the owner picks it up and derives.
-// Heavy bodies end up together in the first waves, the last waves have nothing to do: 2.2 trips instead of 3.75.
-// Every body's arithmetic is untouched, so the results are the bits of k_step.
-// ---------------------------------------------------------------------------
-constexpr uint32_t kRegroupBlock = 256;
-constexpr uint32_t kRegroupKeys = 8;      // sort keys min(count, 8) = 8 .. 1
-constexpr uint32_t kRegroupFields = 28;   // doubles per parked body (the last one holds mask and shape words)
-
-template <bool TRACE>
-__global__ void __launch_bounds__(kRegroupBlock, 2) k_step_regroup(BodyArrays b, ShapeTable shapes, double h, uint32_t substeps,
-                                                                 uint32_t *__restrict__ last_mask,
-                                                                 uint32_t *__restrict__ trace_masks, uint32_t trace_row0)
-{
-    extern __shared__ double lds[]; // parked bodies [kRegroupFields][256], vertex tables, shape offsets, sort counters
-    double *park = lds;
-    double *lds_verts = park + kRegroupFields * kRegroupBlock;
-    uint32_t *lds_off = reinterpret_cast<uint32_t *>(lds_verts + 3 * shapes.total_verts);
-    // [2][4 waves][kRegroupKeys], alternating between substeps: a substep without contacts has no further barrier,
-    // so a wave that is ahead must not overwrite the counters the others are still reading
-    uint32_t *sort_counts = lds_off + shapes.n_shapes + 1;
-    for (uint32_t k = threadIdx.x; k < 3 * shapes.total_verts; k += kRegroupBlock)
-        lds_verts[k] = shapes.verts[k];
-    for (uint32_t k = threadIdx.x; k <= shapes.n_shapes; k += kRegroupBlock)
-        lds_off[k] = shapes.offsets[k];
-    __syncthreads();
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t i = blockIdx.x * kRegroupBlock + tid;
-    const bool live = i < b.n;
-    const uint32_t st = b.stride;
-    const uint32_t body = live ? i : 0u; // idle lanes shadow body 0 (never stored) so that every lane reaches the barriers
-
-    const BodyStatic s = load_static(b, body);
-    BodyDynamic d = load_dynamic(b.dyn, st, body);
-    const uint32_t sid = b.shape_id[body];
-    const uint32_t v0 = lds_off[sid];
-    const uint32_t nv = lds_off[sid + 1] - v0;
-    const double compliance = 1e-6 / (h * h); // src/solver.rs:20
-
-    uint32_t mask = 0;
-    for (uint32_t k = 0; k < substeps; ++k) {
-        const SubstepFrames f = integrate_body(d, s, h);
-        mask = live ? ground_mask(f.cur, lds_verts + 3 * v0, nv) : 0u;
-        uint32_t *sort_count = sort_counts + (k & 1u) * (kRegroupBlock / 64) * kRegroupKeys;
-
-        // ---- rank of this body among the workgroup's bodies with contacts: descending key, then thread order ----
-        const uint32_t count = (uint32_t)__popc(mask);
-        const uint32_t key = count < kRegroupKeys ? count : kRegroupKeys; // 0 = no contacts
-        unsigned long long mine = 0;   // lanes of this wave with my key
-        uint32_t wave_counts = 0;      // lane q < kRegroupKeys: number of lanes of this wave with key q + 1
-        for (uint32_t q = 1; q <= kRegroupKeys; ++q) {
-            const unsigned long long m = __ballot(key == q);
-            if (key == q)
-                mine = m;
-            if (lane == q - 1)
-                wave_counts = (uint32_t)__popcll(m);
-        }
-        if (lane < kRegroupKeys)
-            sort_count[wave * kRegroupKeys + lane] = wave_counts;
-        __syncthreads();
-        uint32_t n_active = 0, rank = 0;
-        for (uint32_t q = kRegroupKeys; q >= 1; --q)
-            for (uint32_t w = 0; w < kRegroupBlock / 64; ++w) {
-                const uint32_t c = sort_count[w * kRegroupKeys + q - 1];
-                if (q > key || (q == key && w < wave))
-                    rank += c; // bodies ahead of mine
-                n_active += c;
-            }
-        rank += (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
-
-        if (n_active) { // workgroup-uniform
-            if (key) {
-                double *p = park + rank;
-                p[0 * kRegroupBlock] = d.pos.x, p[1 * kRegroupBlock] = d.pos.y, p[2 * kRegroupBlock] = d.pos.z;
-                p[3 * kRegroupBlock] = d.rot.s, p[4 * kRegroupBlock] = d.rot.x, p[5 * kRegroupBlock] = d.rot.y, p[6 * kRegroupBlock] = d.rot.z;
-                p[7 * kRegroupBlock] = f.past.position.x, p[8 * kRegroupBlock] = f.past.position.y, p[9 * kRegroupBlock] = f.past.position.z;
-                p[10 * kRegroupBlock] = f.past.rotation.s, p[11 * kRegroupBlock] = f.past.rotation.x;
-                p[12 * kRegroupBlock] = f.past.rotation.y, p[13 * kRegroupBlock] = f.past.rotation.z;
-                p[14 * kRegroupBlock] = s.com.x, p[15 * kRegroupBlock] = s.com.y, p[16 * kRegroupBlock] = s.com.z;
-                p[17 * kRegroupBlock] = s.inv_mass;
-                p[18 * kRegroupBlock] = s.inv_inertia.cx.x, p[19 * kRegroupBlock] = s.inv_inertia.cx.y, p[20 * kRegroupBlock] = s.inv_inertia.cx.z;
-                p[21 * kRegroupBlock] = s.inv_inertia.cy.x, p[22 * kRegroupBlock] = s.inv_inertia.cy.y, p[23 * kRegroupBlock] = s.inv_inertia.cy.z;
-                p[24 * kRegroupBlock] = s.inv_inertia.cz.x, p[25 * kRegroupBlock] = s.inv_inertia.cz.y, p[26 * kRegroupBlock] = s.inv_inertia.cz.z;
-                p[27 * kRegroupBlock] = __hiloint2double((int)v0, (int)mask);
-            }
-            __syncthreads();
-            // lane t adopts the body of rank (t + 64 * turn) mod 256: the ranks are sorted, so the first wave's worth of
-            // them is the heavy one -- `turn` moves it to another wave (= another SIMD of the CU) from substep to
-            // substep and from workgroup to workgroup, otherwise SIMD 0 of every CU would get all the heavy waves
-            const uint32_t adopt = (tid + 64u * ((blockIdx.x + k) & 3u)) & (kRegroupBlock - 1u);
-            if (adopt < n_active) {
-                double *p = park + adopt;
-                Vec3 pos{p[0 * kRegroupBlock], p[1 * kRegroupBlock], p[2 * kRegroupBlock]};
-                Quat rot{p[3 * kRegroupBlock], p[4 * kRegroupBlock], p[5 * kRegroupBlock], p[6 * kRegroupBlock]};
-                const Frame past{Vec3{p[7 * kRegroupBlock], p[8 * kRegroupBlock], p[9 * kRegroupBlock]},
-                                 Quat{p[10 * kRegroupBlock], p[11 * kRegroupBlock], p[12 * kRegroupBlock], p[13 * kRegroupBlock]}};
-                const Vec3 com{p[14 * kRegroupBlock], p[15 * kRegroupBlock], p[16 * kRegroupBlock]};
-                const double inv_mass = p[17 * kRegroupBlock];
-                Mat3 inv_inertia;
-                inv_inertia.cx = Vec3{p[18 * kRegroupBlock], p[19 * kRegroupBlock], p[20 * kRegroupBlock]};
-                inv_inertia.cy = Vec3{p[21 * kRegroupBlock], p[22 * kRegroupBlock], p[23 * kRegroupBlock]};
-                inv_inertia.cz = Vec3{p[24 * kRegroupBlock], p[25 * kRegroupBlock], p[26 * kRegroupBlock]};
-                const double words = p[27 * kRegroupBlock];
-                const uint32_t a_v0 = (uint32_t)__double2hiint(words), a_mask = (uint32_t)__double2loint(words);
-                // the frozen post-integrate frame, as integrate_body formed it (same operands, same bits)
-                const Frame cur{frame_origin(pos, rot, com), rot};
-                solve_masked(pos, rot, inv_mass, inv_inertia, com, cur, past, compliance, lds_verts + 3 * a_v0, a_mask);
-                p[0 * kRegroupBlock] = pos.x, p[1 * kRegroupBlock] = pos.y, p[2 * kRegroupBlock] = pos.z;
-                p[3 * kRegroupBlock] = rot.s, p[4 * kRegroupBlock] = rot.x, p[5 * kRegroupBlock] = rot.y, p[6 * kRegroupBlock] = rot.z;
-            }
-            __syncthreads();
-            if (key) {
-                const double *p = park + rank;
-                d.pos = Vec3{p[0 * kRegroupBlock], p[1 * kRegroupBlock], p[2 * kRegroupBlock]};
-                d.rot = Quat{p[3 * kRegroupBlock], p[4 * kRegroupBlock], p[5 * kRegroupBlock], p[6 * kRegroupBlock]};
-            }
-            // the next substep's parking comes after its own sort barrier, i.e. after these reads
-        }
-        derive_body(d, f.past_pos, f.past_rot, h);
-        if (TRACE && live)
-            trace_masks[(size_t)(trace_row0 + k) * st + i] = mask;
-    }
-
-    if (live) {
-        store_dynamic(b.dyn, st, i, d);
-        last_mask[i] = mask;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // AoS <-> SoA.  A block moves 64 bodies: the 64*38-double AoS chunk is one
 // contiguous range (coalesced) and is transposed through LDS into 38
 // contiguous 512-byte field segments.
@@ -380,23 +243,6 @@ hipError_t launch_step(const BodyArrays &b, const ShapeTable &s, double h, uint3
     else
         hipLaunchKernelGGL(k_step<false>, dim3(grid), dim3(block_size), lds_bytes, stream, b, s, h, substeps,
                            last_mask, trace_masks, trace_row0);
-    return hipGetLastError();
-}
-
-hipError_t launch_step_regroup(const BodyArrays &b, const ShapeTable &s, double h, uint32_t substeps, uint32_t *last_mask,
-                               uint32_t *trace_masks, uint32_t trace_row0, hipStream_t stream)
-{
-    if (b.n == 0)
-        return hipSuccess;
-    const uint32_t grid = (b.n + kRegroupBlock - 1) / kRegroupBlock;
-    const size_t lds_bytes = (size_t)kRegroupFields * kRegroupBlock * sizeof(double) + (size_t)s.total_verts * 3 * sizeof(double) +
-                             (size_t)(s.n_shapes + 1) * sizeof(uint32_t) + (size_t)2 * (kRegroupBlock / 64) * kRegroupKeys * sizeof(uint32_t);
-    if (trace_masks)
-        hipLaunchKernelGGL(k_step_regroup<true>, dim3(grid), dim3(kRegroupBlock), lds_bytes, stream, b, s, h, substeps, last_mask,
-                           trace_masks, trace_row0);
-    else
-        hipLaunchKernelGGL(k_step_regroup<false>, dim3(grid), dim3(kRegroupBlock), lds_bytes, stream, b, s, h, substeps, last_mask,
-                           trace_masks, trace_row0);
     return hipGetLastError();
 }
 

@@ -84,7 +84,6 @@ struct xpbd_world {
     uint32_t mode = XPBD_MODE_FUSED;
     uint32_t flags = 0;
     uint32_t block_size = 0;
-    bool regroup = false; // fused stepper with per-substep regrouping of the contact work (k_step_regroup)
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -350,8 +349,6 @@ int xpbd_world_create(xpbd_world **out, const xpbd_config *cfg)
     w->mode = c.mode;
     w->flags = c.flags;
     w->block_size = c.block_size ? c.block_size : kDefaultBlock;
-    if (const char *e = std::getenv("XPBD_STEP_REGROUP"))
-        w->regroup = e[0] == '1';
     e = hipSetDevice(w->device);
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking);
@@ -665,9 +662,6 @@ int xpbd_world_step(xpbd_world *w, double dt, uint32_t substeps)
     if (w->mode == XPBD_MODE_CONTACTS) {
         if (int rc = step_contacts(w, dt, h, substeps, trace))
             return rc;
-    } else if (w->mode == XPBD_MODE_FUSED && w->regroup) {
-        XPBD_HIP_TRY(xpbd::launch_step_regroup(w->arrays(), w->shapes(), h, substeps, w->last_mask.as<uint32_t>(), trace, 0,
-                                               w->stream));
     } else if (w->mode == XPBD_MODE_FUSED) {
         XPBD_HIP_TRY(xpbd::launch_step(w->arrays(), w->shapes(), h, substeps, w->last_mask.as<uint32_t>(), trace, 0,
                                        w->block_size, w->stream));
