@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
+    "xpbd_world_set_sat_schedule",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
 
@@ -134,6 +135,7 @@ def hip_lib():
         L.xpbd_world_contacts_substep.argtypes = [C.c_void_p, C.c_double]
         L.xpbd_world_export_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.xpbd_world_import_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_set_sat_schedule.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_world_history_push.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.xpbd_world_history_restore.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_world_history_truncate.argtypes = [C.c_void_p, C.c_uint32]
@@ -317,6 +319,10 @@ class World:
     def import_dynamic(self, dev_indices_ptr, n, dev_buf_ptr):
         _check(hip_lib().xpbd_world_import_dynamic(self._h, C.c_void_p(dev_indices_ptr), n, C.c_void_p(dev_buf_ptr)))
 
+    def set_sat_schedule(self, schedule):
+        """SAT_SCHEDULE_AUTO / _ONE_PASS / _TWO_PASS (same results, different cost)."""
+        _check(hip_lib().xpbd_world_set_sat_schedule(self._h, schedule))
+
     # state history: the reference app's `states` vector and `current_state` cursor (src/app.rs:48, 206-212)
     def history_push(self):
         index = C.c_uint32(0)
@@ -357,6 +363,7 @@ def selftest_div_sqrt(a, b, device=0):
 
 
 # ---- host mirror (CPU set-up math; no GPU needed) -------------------------------
+SAT_SCHEDULE_AUTO, SAT_SCHEDULE_ONE_PASS, SAT_SCHEDULE_TWO_PASS = 0, 1, 2
 SCENE_BOXES, SCENE_MIXED, SCENE_BOXES_DROP, SCENE_MIXED_DROP, SCENE_BOX_STACKS = 0, 1, 2, 3, 4
 SHAPE_CUBE, SHAPE_TETRAHEDRON, SHAPE_ICOSAHEDRON = 0, 1, 2
 

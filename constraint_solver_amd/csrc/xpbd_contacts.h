@@ -61,8 +61,9 @@ hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, h
 hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
                                    uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream);
 // SAT of every neighbour pair on the post-integrate frames
+// (list: NULL = pre-test inside the SAT kernel, else the two-pass form of launch_sat_pairs)
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
-                                    uint32_t n_pairs, hipStream_t stream);
+                                    uint32_t n_pairs, SatScratch *list, hipStream_t stream);
 // Jacobi pair solve (reads b.dyn = pose', writes dyn_out) + derive
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
                                     hipStream_t stream);

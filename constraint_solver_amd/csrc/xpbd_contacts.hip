@@ -699,9 +699,9 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
 }
 
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
-                                    uint32_t n_pairs, hipStream_t stream)
+                                    uint32_t n_pairs, SatScratch *list, hipStream_t stream)
 {
-    return launch_sat_pairs(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, c.stats, stream);
+    return launch_sat_pairs(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, c.stats, true, list, stream);
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,

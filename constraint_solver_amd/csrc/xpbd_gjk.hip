@@ -222,7 +222,8 @@ __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const M
 
 // Boolean GJK, L lanes per pair.  out / manifolds (each optional) receive the verdict of every pair that is NOT
 // penetrating; a penetrating pair goes to the hit list with its simplex and is finished by k_epa_pairs.
-template <uint32_t L>
+// PRETEST (contact pipeline only): as in k_sat_pairs, disjoint tight bounding spheres mean "separated" at once.
+template <uint32_t L, bool PRETEST>
 __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                   GjkResult *__restrict__ out, Manifold *__restrict__ manifolds,
@@ -245,7 +246,13 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
         sa = b.shape_id[ia], sb = b.shape_id[ib];
         da = t.desc[sa], db = t.desc[sb];
     }
-    const bool usable = live && da.n_verts != 0 && db.n_verts != 0;
+    bool usable = live && da.n_verts != 0 && db.n_verts != 0;
+    if (PRETEST && usable) {
+        const double *ca = t.centroids + 3 * (size_t)sa, *cb = t.centroids + 3 * (size_t)sb;
+        const Vec3 between = fb * Vec3{cb[0], cb[1], cb[2]} - fa * Vec3{ca[0], ca[1], ca[2]};
+        const double reach = t.radii[sa] + t.radii[sb];
+        usable = dot(between, between) < reach * reach;
+    }
     if (usable)
         stage_world_vertices(s, t, da, db, fa, fb, lane, L);
     __syncthreads();
@@ -529,7 +536,8 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
 size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 12 + 8; }
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, GjkScratch &scratch, hipStream_t stream)
+                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
+                                hipStream_t stream)
 {
     if (n_pairs == 0)
         return hipSuccess;
@@ -537,12 +545,15 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + n_pairs);
     uint32_t *count = scratch.counters + (scratch.calls & 1u), *next = scratch.counters + ((scratch.calls + 1u) & 1u);
     ++scratch.calls;
-    if (t.max_verts <= 16) // 16 lanes per pair, four pairs per wave
-        hipLaunchKernelGGL(k_gjk_pairs<16>, dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
-                           manifolds, count, hits, seeds);
+    const dim3 grid16((n_pairs + 3) / 4), grid32((n_pairs + 1) / 2);
+    if (t.max_verts <= 16 && sphere_pretest) // 16 lanes per pair, four pairs per wave
+        hipLaunchKernelGGL((k_gjk_pairs<16, true>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
+    else if (t.max_verts <= 16)
+        hipLaunchKernelGGL((k_gjk_pairs<16, false>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
+    else if (sphere_pretest)
+        hipLaunchKernelGGL((k_gjk_pairs<32, true>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
     else
-        hipLaunchKernelGGL(k_gjk_pairs<32>, dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out,
-                           manifolds, count, hits, seeds);
+        hipLaunchKernelGGL((k_gjk_pairs<32, false>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
     hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, next, hits,
                        seeds);

@@ -55,7 +55,21 @@ struct Manifold {
 // Block-reduced statistics of a manifold array: stats[0] += touching pairs, stats[1] += contact points.
 hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream);
 
+// Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two uint32, zero when
+// idle; launch k appends through counters[k & 1] and its SAT kernel zeroes counters[(k + 1) & 1] for the next launch
+// (all launches of one world are stream-ordered).  `survivors`: n_pairs uint32.
+struct SatScratch {
+    uint32_t *counters;
+    uint32_t *survivors;
+    uint32_t calls;
+};
+
+// sphere_pretest: answer "no contact" for pairs whose tight bounding spheres are disjoint (the contact pipeline's
+// semantics; the diagnostic entry point xpbd_world_narrowphase runs the full query on every pair).  With `list` the
+// pre-test runs as a pass of its own and the SAT only over the surviving pairs -- same results, worth it when most
+// pairs fail the test (a scene of loose bodies), a few per cent slower when most pass (stacks).
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream);
+                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, bool sphere_pretest, SatScratch *list,
+                            hipStream_t stream);
 
 } // namespace xpbd

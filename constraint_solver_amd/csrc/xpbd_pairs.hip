@@ -109,30 +109,17 @@ __device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint3
 
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
-// L = lanes per pair: 64 (one pair per wave; any shapes), 32, or 16 (FOUR pairs per wave: for boxes every stage --
-// 8 + 8 vertices, 6 + 6 faces, 3 x 3 edge axes, <= 16 polygon points -- fits in 16 lanes, so a whole wave per
-// pair would idle 3/4 of its lanes).  All loops stride by the group width and all shuffles stay inside the
-// group, so both instantiations produce the same bits.  The block is ONE wave, hence __syncthreads() is a
-// wave-local fence and the sub-waves of a wave may diverge freely (one pair separated, the next one clipping).
-template <uint32_t L, uint32_t V>
-__global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(BodyArrays b, PolytopeTables t,
-                                                                               const double *__restrict__ frames,
-                                                                               const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                                               Manifold *__restrict__ out)
+// The SAT of ONE pair by a group of L lanes (`lane` = lane inside the group, `s` = the group's LDS record).
+// L = 64 (any shapes), 32, or 16 (for boxes every stage -- 8 + 8 vertices, 6 + 6 faces, 3 x 3 edge axes, <= 16 polygon
+// points -- fits in 16 lanes, so a whole wave per pair would idle 3/4 of its lanes).  All loops stride by the group
+// width and all shuffles stay inside the group, so every instantiation produces the same bits.  The block is ONE
+// wave, hence __syncthreads() is a wave-local fence and the groups of a wave may diverge freely (one pair separated,
+// the next one clipping).
+template <uint32_t L, class Lds>
+__device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
+                                         const uint32_t *__restrict__ pairs, uint32_t p, Manifold *__restrict__ out, uint32_t lane)
 {
-    constexpr uint32_t H = L / 2;        // lanes per body in the two-sided stages
-    constexpr uint32_t PW = 64 / L;      // pairs per wave
-    static_assert(V == 8 || V == 16 || V == kMaxV, "vertex capacity per body");
-    // record size in dwords is a multiple of 64 for every V above: pad by 64 / PW dwords (two dwords keep 8-byte alignment)
-    using Lds = PairLds<V, PW == 1 ? 0u : 64u / PW>;
-    static_assert(sizeof(Lds) % 8 == 0, "pair records must stay 8-byte aligned");
-    __shared__ Lds s_all[PW];
-    Lds &s = s_all[threadIdx.x / L];
-    const uint32_t p = blockIdx.x * PW + threadIdx.x / L;
-    const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
-    if (p >= n_pairs)
-        return;
-
+    constexpr uint32_t H = L / 2; // lanes per body in the two-sided stages
     // ---- group-uniform inputs ---------------------------------------------------------------------
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
@@ -405,6 +392,112 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(B
     m->separation = face_best;
 }
 
+// Tight bounding spheres (centroid, largest vertex distance; no velocity term, no pad) of pair p overlap?  The neighbour
+// lists come from spheres inflated by a whole frame of travel, so in a given substep most pairs of a loose scene are
+// nowhere near each other (mixed scene: three in four).  Disjoint spheres cannot touch: the contact pipeline answers
+// "no contact" for them without running the SAT (semantics: op_contacts_substep of the oracle).
+__device__ __forceinline__ bool tight_spheres_overlap(const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
+                                                      const uint32_t *__restrict__ pairs, uint32_t p)
+{
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
+    const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
+    const double *ca = t.centroids + 3 * (size_t)sa, *cb = t.centroids + 3 * (size_t)sb;
+    const Vec3 between = load_frame(frames, b.stride, ib) * Vec3{cb[0], cb[1], cb[2]} - load_frame(frames, b.stride, ia) * Vec3{ca[0], ca[1], ca[2]};
+    const double reach = t.radii[sa] + t.radii[sb];
+    return dot(between, between) < reach * reach;
+}
+
+template <uint32_t L, uint32_t V>
+struct SatLds {
+    static constexpr uint32_t PW = 64 / L; // pairs per wave
+    static_assert(V == 8 || V == 16 || V == kMaxV, "vertex capacity per body");
+    // record size in dwords is a multiple of 64 for every V above: pad by 64 / PW dwords (two dwords keep 8-byte alignment)
+    using Record = PairLds<V, PW == 1 ? 0u : 64u / PW>;
+    static_assert(sizeof(Record) % 8 == 0, "pair records must stay 8-byte aligned");
+};
+
+// One group of L lanes per pair, 64 / L pairs per wave, pairs in list order.  PRETEST: the contact pipeline's form.
+template <uint32_t L, uint32_t V, bool PRETEST>
+__global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(BodyArrays b, PolytopeTables t,
+                                                                               const double *__restrict__ frames,
+                                                                               const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                                               Manifold *__restrict__ out)
+{
+    using Lds = typename SatLds<L, V>::Record;
+    __shared__ Lds s_all[SatLds<L, V>::PW];
+    const uint32_t group = threadIdx.x / L, lane = threadIdx.x % L;
+    const uint32_t p = blockIdx.x * SatLds<L, V>::PW + group;
+    if (p >= n_pairs)
+        return;
+    if (PRETEST && !tight_spheres_overlap(b, t, frames, pairs, p)) {
+        if (lane == 0)
+            out[p].n_points = 0;
+        return;
+    }
+    sat_pair<L>(s_all[group], b, t, frames, pairs, p, out, lane);
+}
+
+// The pre-test as a pass of its own, one LANE per pair: rejected pairs are answered, the others are appended to a
+// survivor list.  ONE atomic per 1024-pair workgroup (same-address atomics serialise at ~10-25 ns each: one per wave
+// made this pass 25 us for 50 000 pairs); the order of the list is irrelevant, results go to out[p].
+constexpr uint32_t kPretestBlock = 1024;
+
+__global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+                                                                const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                                Manifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
+                                                                uint32_t *__restrict__ survivors)
+{
+    __shared__ uint32_t wave_base[kPretestBlock / 64 + 1];
+    const uint32_t p = blockIdx.x * kPretestBlock + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool keep = false;
+    if (p < n_pairs) {
+        keep = tight_spheres_overlap(b, t, frames, pairs, p);
+        if (!keep)
+            out[p].n_points = 0;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0)
+        wave_base[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) { // exclusive scan of the 16 wave counts, then one atomic for the whole workgroup
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < kPretestBlock / 64; ++w) {
+            const uint32_t c = wave_base[w];
+            wave_base[w] = run;
+            run += c;
+        }
+        const uint32_t base = run ? atomicAdd(survivor_count, run) : 0u;
+        wave_base[kPretestBlock / 64] = base;
+    }
+    __syncthreads();
+    if (keep)
+        survivors[wave_base[kPretestBlock / 64] + wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+}
+
+// ... and the SAT over the survivors only, so that every group of every wave has a pair that needs it.  The grid is
+// sized for all pairs (the count lives on the device); blocks past the survivors leave at once.  Block 0 zeroes the
+// counter of the NEXT launch (the two counters alternate, as in xpbd_gjk.hip).
+template <uint32_t L, uint32_t V>
+__global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivors(BodyArrays b, PolytopeTables t,
+                                                                                   const double *__restrict__ frames,
+                                                                                   const uint32_t *__restrict__ pairs,
+                                                                                   const uint32_t *__restrict__ survivor_count,
+                                                                                   uint32_t *__restrict__ next_survivor_count,
+                                                                                   const uint32_t *__restrict__ survivors,
+                                                                                   Manifold *__restrict__ out)
+{
+    using Lds = typename SatLds<L, V>::Record;
+    __shared__ Lds s_all[SatLds<L, V>::PW];
+    const uint32_t group = threadIdx.x / L, lane = threadIdx.x % L;
+    const uint32_t k = blockIdx.x * SatLds<L, V>::PW + group;
+    const uint32_t n = *survivor_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *next_survivor_count = 0;
+    if (k >= n)
+        return;
+    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[k], out, lane);
+}
+
 // stats[0] += pairs with contact points, stats[1] += contact points.  Same-address atomics serialise at
 // the memory side (~10 ns each): never one per pair (that WAS the whole narrowphase launch once), and
 // not even one per 256 pairs -- a grid-stride loop over at most kStatsBlocks blocks, one atomic pair each.
@@ -445,20 +538,42 @@ hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned l
     return hipGetLastError();
 }
 
+namespace {
+// kind: 0 = every pair, full query; 1 = in-group sphere pre-test; 2 = pre-test pass + survivor list
+template <uint32_t L, uint32_t V>
+void launch_sat_kernels(int kind, const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                        uint32_t n_pairs, Manifold *out, SatScratch *list, hipStream_t stream)
+{
+    const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
+    if (kind == 2) {
+        uint32_t *count = list->counters + (list->calls & 1u), *next = list->counters + ((list->calls + 1u) & 1u);
+        ++list->calls;
+        hipLaunchKernelGGL(k_pair_pretest, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
+                           frames, pairs, n_pairs, out, count, list->survivors);
+        hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, out);
+    } else if (kind == 1) {
+        hipLaunchKernelGGL((k_sat_pairs<L, V, true>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+    } else {
+        hipLaunchKernelGGL((k_sat_pairs<L, V, false>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+    }
+}
+} // namespace
+
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, hipStream_t stream)
+                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, bool sphere_pretest, SatScratch *list,
+                            hipStream_t stream)
 {
     if (n_pairs) {
+        const int kind = !sphere_pretest ? 0 : (list ? 2 : 1);
         // lanes per pair and vertex capacity by the largest shape: boxes and tetrahedra (<= 8 vertices and faces) run
         // four pairs per wave with 8-vertex records; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
         // 16-vertex records; anything larger gets a whole wave
         if (t.max_verts <= 8 && t.max_faces <= 8)
-            hipLaunchKernelGGL((k_sat_pairs<16, 8>), dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+            launch_sat_kernels<16, 8>(kind, b, t, frames, pairs, n_pairs, out, list, stream);
         else if (t.max_verts <= 16)
-            hipLaunchKernelGGL((k_sat_pairs<XPBD_SAT_MID_LANES, 16>), dim3((n_pairs + 64 / XPBD_SAT_MID_LANES - 1) / (64 / XPBD_SAT_MID_LANES)),
-                               dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+            launch_sat_kernels<XPBD_SAT_MID_LANES, 16>(kind, b, t, frames, pairs, n_pairs, out, list, stream);
         else
-            hipLaunchKernelGGL((k_sat_pairs<64, kMaxV>), dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+            launch_sat_kernels<64, kMaxV>(kind, b, t, frames, pairs, n_pairs, out, list, stream);
         if (stats) {
             const uint32_t nb = (n_pairs + 255) / 256;
             hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);

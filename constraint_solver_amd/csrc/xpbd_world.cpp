@@ -127,6 +127,13 @@ struct xpbd_world {
     uint32_t history_length = 0;
     std::vector<uint8_t> history_stepped;
     size_t history_slot_bytes() const { return ((size_t)xpbd::kDynFields * stride * 8 + (size_t)stride * 4 + 255) / 256 * 256; }
+    // SAT in two passes (pre-test pass + survivor list, xpbd_pairs.h): chosen per frame from the share of touching
+    // pairs in the previous frame, read back at the broadphase's synchronisation point
+    DeviceBuffer sat_counters, sat_survivors;
+    xpbd::SatScratch sat_scratch{nullptr, nullptr, 0};
+    bool sat_two_pass = false;
+    uint32_t sat_schedule = XPBD_SAT_SCHEDULE_AUTO;
+    unsigned long long stats_touching_seen = 0, stats_pair_substeps = 0, stats_pair_substeps_seen = 0;
     DeviceBuffer gjk_counters, gjk_pairs_scratch;   // hit list of the two-kernel GJK/EPA narrowphase (xpbd_gjk.h)
     xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0};
     xpbd::ContactBuffers contact_buffers() const
@@ -228,6 +235,8 @@ int build_neighbours(xpbd_world *w, double dt)
     if (!w->cb_stats.ptr) {
         XPBD_HIP_TRY(w->cb_stats.reserve(16));
         XPBD_HIP_TRY(hipMemsetAsync(w->cb_stats.ptr, 0, 16, w->stream));
+        w->stats_touching_seen = 0;
+        w->stats_pair_substeps_seen = w->stats_pair_substeps;
     }
     const xpbd::BodyArrays b = w->arrays();
     xpbd::ContactBuffers c = w->contact_buffers();
@@ -236,11 +245,34 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(xpbd::launch_build_buckets(b, c, w->stream));
     XPBD_HIP_TRY(xpbd::launch_neighbour_count(b, c, w->stream));
     uint32_t totals[2] = {0, 0};
+    unsigned long long stats_now[2] = {0, 0};
     XPBD_HIP_TRY(hipMemcpyAsync(&totals[0], c.nbr_off + n, 4, hipMemcpyDeviceToHost, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(&totals[1], c.pair_first + n, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(stats_now, c.stats, 16, hipMemcpyDeviceToHost, w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     w->n_entries = totals[0];
     w->n_pairs = totals[1];
+    {
+        // Two-pass SAT for the coming frame?  Yes when few of the pairs examined since the last broadphase were
+        // touching (loose bodies: most pairs fail the sphere pre-test); no for packed scenes.  Either way the results
+        // are the same bits; this only picks the cheaper schedule.
+        const unsigned long long touching = stats_now[0] - w->stats_touching_seen;
+        const unsigned long long examined = w->stats_pair_substeps - w->stats_pair_substeps_seen;
+        if (w->sat_schedule != XPBD_SAT_SCHEDULE_AUTO)
+            w->sat_two_pass = w->sat_schedule == XPBD_SAT_SCHEDULE_TWO_PASS;
+        else if (examined)
+            w->sat_two_pass = touching * 4 < examined;
+        w->stats_touching_seen = stats_now[0];
+        w->stats_pair_substeps_seen = w->stats_pair_substeps;
+    }
+    if (!w->sat_counters.ptr) {
+        XPBD_HIP_TRY(w->sat_counters.reserve(8));
+        XPBD_HIP_TRY(hipMemsetAsync(w->sat_counters.ptr, 0, 8, w->stream));
+        w->sat_scratch.calls = 0;
+    }
+    XPBD_HIP_TRY(w->sat_survivors.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 4));
+    w->sat_scratch.counters = w->sat_counters.as<uint32_t>();
+    w->sat_scratch.survivors = w->sat_survivors.as<uint32_t>();
     XPBD_HIP_TRY(w->cb_nbr.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_nbr_pair.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_pairs.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 8));
@@ -261,13 +293,15 @@ int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_ro
         if (int rc = ensure_gjk_scratch(w, w->n_pairs))
             return rc;
         XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds,
-                                                w->gjk_scratch, w->stream));
+                                                w->gjk_scratch, true, w->stream));
         XPBD_HIP_TRY(xpbd::launch_manifold_stats(c.manifolds, w->n_pairs, c.stats, w->stream));
     } else {
-        XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->stream));
+        XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
+                                                    w->stream));
     }
     XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
     std::swap(w->dyn, w->dyn_alt);
+    w->stats_pair_substeps += w->n_pairs;
     return XPBD_OK;
 }
 
@@ -376,7 +410,8 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
-                            &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history})
+                            &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
+                            &w->sat_counters, &w->sat_survivors})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
@@ -552,7 +587,7 @@ int xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pair
     XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * w->stride * 8));
     XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
     XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(), w->pair_buf.as<uint32_t>(),
-                                        n_pairs, w->manifold_buf.as<xpbd::Manifold>(), nullptr, w->stream));
+                                        n_pairs, w->manifold_buf.as<xpbd::Manifold>(), nullptr, false, nullptr, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::Manifold),
                                 hipMemcpyDeviceToHost, w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
@@ -809,7 +844,7 @@ int xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_
         return rc;
     XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(),
                                             w->pair_buf.as<uint32_t>(), n_pairs, w->manifold_buf.as<xpbd::GjkResult>(),
-                                            nullptr, w->gjk_scratch, w->stream));
+                                            nullptr, w->gjk_scratch, false, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::GjkResult), hipMemcpyDeviceToHost,
                                 w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
@@ -900,6 +935,16 @@ int xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32
     return XPBD_OK;
 }
 
+int xpbd_world_set_sat_schedule(xpbd_world *w, uint32_t schedule)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_sat_schedule: NULL world");
+    if (schedule > XPBD_SAT_SCHEDULE_TWO_PASS)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_sat_schedule: unknown schedule %u", schedule);
+    w->sat_schedule = schedule;
+    return XPBD_OK;
+}
+
 int xpbd_world_set_narrowphase(xpbd_world *w, uint32_t narrowphase)
 {
     if (!w || (narrowphase != XPBD_NARROWPHASE_SAT && narrowphase != XPBD_NARROWPHASE_GJK_EPA))
@@ -929,6 +974,8 @@ int xpbd_world_contact_stats(xpbd_world *w, uint64_t out[3])
     unsigned long long host[2] = {0, 0};
     XPBD_HIP_TRY(hipMemcpyAsync(host, w->cb_stats.ptr, 16, hipMemcpyDeviceToHost, w->stream));
     XPBD_HIP_TRY(hipMemsetAsync(w->cb_stats.ptr, 0, 16, w->stream));
+    w->stats_touching_seen = 0; // the schedule heuristic of build_neighbours starts counting afresh
+    w->stats_pair_substeps_seen = w->stats_pair_substeps;
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     out[1] = host[0];
     out[2] = host[1];

@@ -138,6 +138,7 @@ extern "C" {
     pub fn xpbd_world_narrowphase(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdManifold) -> c_int;
     pub fn xpbd_world_narrowphase_gjk(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdGjkResult) -> c_int;
     pub fn xpbd_world_set_narrowphase(w: *mut XpbdWorld, narrowphase: u32) -> c_int;
+    pub fn xpbd_world_set_sat_schedule(w: *mut XpbdWorld, schedule: u32) -> c_int;
     pub fn xpbd_world_set_contact_pad(w: *mut XpbdWorld, pad: f64) -> c_int;
     pub fn xpbd_world_contact_stats(w: *mut XpbdWorld, out: *mut u64) -> c_int;
     pub fn xpbd_world_build_neighbours(w: *mut XpbdWorld, dt: f64, n_entries_out: *mut u32) -> c_int;

@@ -515,12 +515,19 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
                 uint32_t j = nb[k];
                 if (j <= i)
                     continue;
-                if (f->narrowphase == OP_NARROWPHASE_GJK_EPA)
-                    gjk_manifold(p1[i], p1[j], &shapes[shape_id ? shape_id[i] : 0], &shapes[shape_id ? shape_id[j] : 0],
-                                 &manifolds[q]);
+                const o_polytope *pa = &shapes[shape_id ? shape_id[i] : 0], *pb = &shapes[shape_id ? shape_id[j] : 0];
+                /* Pre-test with the TIGHT bounding spheres (centroid, largest vertex distance; no velocity term, no
+                 * pad): the neighbour lists are built once per frame from spheres inflated by the travel of a whole
+                 * frame, so in most substeps most pairs are nowhere near each other.  Disjoint spheres cannot touch. */
+                o_vec3 between = o_sub(o_frame_mulv(p1[j], pb->centroid), o_frame_mulv(p1[i], pa->centroid));
+                double reach = shape_radius(pa) + shape_radius(pb);
+                if (!(o_dot(between, between) < reach * reach)) {
+                    memset(&manifolds[q], 0, sizeof manifolds[q]);
+                    manifolds[q].separated = 1;
+                } else if (f->narrowphase == OP_NARROWPHASE_GJK_EPA)
+                    gjk_manifold(p1[i], p1[j], pa, pb, &manifolds[q]);
                 else
-                    op_sat(p1[i], p1[j], &shapes[shape_id ? shape_id[i] : 0], &shapes[shape_id ? shape_id[j] : 0],
-                           &manifolds[q]);
+                    op_sat(p1[i], p1[j], pa, pb, &manifolds[q]);
                 if (manifolds[q].separated)
                     manifolds[q].n_points = 0;
                 if (stats && manifolds[q].n_points) {

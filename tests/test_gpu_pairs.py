@@ -183,6 +183,29 @@ def test_contact_pipeline_pile_matches_oracle(kind, n, width):
     assert sum(s[1] for s in ws) > 100 and sum(s[2] for s in ws) > 200   # bodies really did collide
 
 
+@pytest.mark.parametrize("kind,n,width", [(capi.SCENE_MIXED_DROP, 300, 6.0), (capi.SCENE_BOXES_DROP, 120, 2.0)])
+def test_sat_schedules_give_identical_results(kind, n, width):
+    """The sphere pre-test inside the SAT kernel, as a pass of its own with a survivor list, and whatever AUTO picks
+    from frame to frame: same bits, all equal to the oracle (which pre-tests every pair before its SAT)."""
+    bodies, sid = pile(kind, n, 21, width, 8.0)
+    polys = ob.polytopes_array(POLY_NAMES[kind])
+    want = bodies
+    for _ in range(12):
+        want, _, st = ob.contacts_step(want, sid, polys, DT, 8, 0.02)
+    results = []
+    for schedule in (capi.SAT_SCHEDULE_ONE_PASS, capi.SAT_SCHEDULE_TWO_PASS, capi.SAT_SCHEDULE_AUTO):
+        with capi.World(mode=capi.MODE_CONTACTS) as w:
+            w.set_polytopes(capi.scene_polytopes(kind))
+            w.set_sat_schedule(schedule)
+            w.upload(bodies, sid)
+            for _ in range(12):
+                w.step(DT, 8)
+            results.append(w.download())
+            with pytest.raises(capi.XpbdError):
+                w.set_sat_schedule(3)
+    assert all(bits_equal(r, want) for r in results)
+
+
 def test_contact_pipeline_dense_clump_matches_oracle():
     """150 boxes in one clump: neighbour lists of 149 entries (beyond the 128-entry LDS stage of the neighbour fill),
     11 175 pairs; pair order, manifolds and the Jacobi sums must still be the oracle's."""
