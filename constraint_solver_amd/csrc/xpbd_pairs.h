@@ -50,7 +50,7 @@ struct Manifold {
     double p_inc[kMaxManifoldPoints][3];
 };
 
-// One wave per pair: pairs[2*p], pairs[2*p+1] are body indices (A, B).  frames: [7][stride] object->world
+// pairs[2*p], pairs[2*p+1] are body indices (A, B); 16, 32 or 64 lanes per pair.  frames: [7][stride] object->world
 // frames of all bodies (origin xyz, rotation s x y z).  stats (optional): [0] += touching pairs, [1] += points.
 // Block-reduced statistics of a manifold array: stats[0] += touching pairs, stats[1] += contact points.
 hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream);

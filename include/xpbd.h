@@ -189,13 +189,15 @@ typedef struct xpbd_manifold {
 int  xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_t n_shapes);
 
 /* SAT narrowphase of the given body pairs (pairs[2k], pairs[2k+1] = A, B) at the
- * world's current poses: one wave per pair.  out has n_pairs entries. */
+ * world's current poses: a group of 16, 32 or 64 lanes per pair (by the largest shape).
+ * out has n_pairs entries. */
 int  xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs,
                             xpbd_manifold *out);
 
 /* GJK + EPA narrowphase of the given pairs (the reference has neither): boolean GJK on the
  * Minkowski difference built with the reference's support convention (src/geometry.rs:274-289), then EPA for the
- * penetration depth, the normal (from A to B) and one witness point on each body.  One wave per pair. */
+ * penetration depth, the normal (from A to B) and one witness point on each body.  16 or 32 lanes per pair
+ * for the boolean GJK, one wave per penetrating pair for EPA. */
 #define XPBD_GJK_SEPARATED   0
 #define XPBD_GJK_PENETRATING 1
 #define XPBD_GJK_DEGENERATE  2  /* origin on the simplex boundary / flat simplex / iteration cap: use the SAT */
