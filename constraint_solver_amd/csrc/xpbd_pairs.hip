@@ -42,7 +42,8 @@ struct PairLds {
     double world[2][V][3]; // world-space vertices of A (0) and B (1)
     double local[2][V][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space
     double poly[2][16][3]; // clipping ping-pong
-    uint32_t pad[PAD ? PAD : 1];
+    double ref[kMaxFaceVerts][3]; // the reference face's vertices, staged once for the clipping loop
+    uint32_t pad[16 + (PAD ? PAD : 1)]; // 16: `ref` is 48 dwords, this keeps the unpadded record a multiple of 64
 };
 
 __device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
@@ -322,11 +323,15 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
     if (lane < np)
         st3(s.poly[0], lane, ld3(s.world[r ^ 1u], iv[lane]));
+    // the reference face's vertices by index once, lane-parallel: the clipping loop below then reads LDS only
+    // (phase timing: the three dependent global index loads per side plane were ~40 % of the loop)
+    if (lane < nr && lane < kMaxFaceVerts)
+        st3(s.ref, lane, ld3(s.world[r], rv[lane]));
     __syncthreads();
     uint32_t cur = 0;
     for (uint32_t e = 0; e < nr && np > 0; ++e) {
-        const Vec3 a = ld3(s.world[r], rv[e]), bnext = ld3(s.world[r], rv[(e + 1) % nr]);
-        const Vec3 c = ld3(s.world[r], rv[(e + 2) % nr]);
+        const Vec3 a = ld3(s.ref, e), bnext = ld3(s.ref, (e + 1) % nr);
+        const Vec3 c = ld3(s.ref, (e + 2) % nr);
         Vec3 side = cross(bnext - a, ref_plane.normal);
         if (dot(side, c - a) > 0.0)
             side = -side;
