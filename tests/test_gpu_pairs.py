@@ -530,3 +530,37 @@ def test_narrowphases_on_random_convex_hulls():
             hits += 1
             assert bits_equal(np.array([g["depth"]]), np.array([r.depth])) and bits_equal(g["point_a"], r.point_a.np())
     assert hits > 200
+
+
+@pytest.mark.parametrize("narrowphase", [capi.NARROWPHASE_SAT, capi.NARROWPHASE_GJK_EPA])
+def test_contact_pipeline_on_random_hulls_with_whole_wave_groups(narrowphase):
+    """Shapes above 16 vertices select the widest kernels (64 lanes per pair for the SAT with 32-vertex records, 32
+    lanes for the boolean GJK): a pile of random 18-, 16- and 10-vertex hulls through the whole pipeline, under every
+    SAT schedule, against the oracle."""
+    import hull_util as hu
+    raw = [hu.random_hull(7, 18, 0.6), hu.random_hull(8, 16, 0.5), hu.random_hull(9, 10, 0.4)]
+    polys = (ob.Polytope * 3)(*[hu.as_oracle(*h) for h in raw])
+    n = 90
+    bodies, _ = capi.scene_generate(capi.SCENE_BOXES_DROP, 5, n)
+    rng = np.random.default_rng(33)
+    bodies[:, 31:33] = rng.uniform(0.0, 2.5, (n, 2))
+    bodies[:, 33] = rng.uniform(0.7, 5.0, n)
+    bodies[:, 22:25] *= 0.3
+    bodies[:, 28:31] = 0.0                                          # the hulls are centred: com = 0
+    sid = (np.arange(n) % 3).astype(np.uint32)
+    want = bodies
+    for _ in range(6):
+        want = ob.contacts_step_joints(want, sid, polys, np.zeros(0, dtype=capi.JOINT_DTYPE), DT, 8, 0.02, narrowphase=int(narrowphase))
+    schedules = (capi.SAT_SCHEDULE_ONE_PASS, capi.SAT_SCHEDULE_TWO_PASS) if narrowphase == capi.NARROWPHASE_SAT else (capi.SAT_SCHEDULE_AUTO,)
+    touched = 0
+    for schedule in schedules:
+        with capi.World(mode=capi.MODE_CONTACTS) as w:
+            w.set_polytopes([hu.as_capi(*h) for h in raw])
+            w.set_narrowphase(narrowphase)
+            w.set_sat_schedule(schedule)
+            w.upload(bodies, sid)
+            for _ in range(6):
+                w.step(DT, 8)
+            assert bits_equal(w.download(), want)
+            touched = w.contact_stats()[1]
+    assert touched > 50                                             # hulls really did collide
