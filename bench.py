@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- body*substeps/s of the XPBD stepper hot path on N MI355X GPUs of one node.
+"""bench.py -- body\u00b7substeps/s of the XPBD stepper hot path on N MI355X GPUs of one node.
 
 A "step" is one frame: xpbd_world_step(dt = 1/60, substeps) over the rank's resident
 bodies, i.e. for every body `solver::step(body, shape, dt, substeps)` (reference
@@ -25,6 +25,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BASELINE.json's metric, verbatim (the file travels with the repo; the constant is the fallback)
+METRIC = "body\u00b7substeps/sec at 262k rigid bodies, 20 substeps/frame; 1/2/4/8 GPU"
+try:
+    with open(os.path.join(ROOT, "BASELINE.json")) as _f:
+        METRIC = json.load(_f).get("metric", METRIC)
+except (OSError, ValueError):
+    pass
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FRAME_TIME = 1.0 / 60.0  # reference src/app.rs:15
 
@@ -61,7 +68,7 @@ def cpu_baseline(state, shape_id, verts, offsets, substeps, budget_s=12.0, sampl
     for _ in range(frames):
         bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps)
     sec = time.perf_counter() - t0
-    out = {"value": n * substeps * frames / sec, "unit": "body*substeps/s", "cores": 1, "kind": "port",
+    out = {"value": n * substeps * frames / sec, "unit": "body\u00b7substeps/s", "cores": 1, "kind": "port",
            "sample": "first %d bodies of the benchmark state after warmup, %d frames x %d substeps, %.1f s, "
                      "oracle/xpbd_oracle.c (C restatement of the reference, gcc -O2 -ffp-contract=off), 1 thread "
                      "like the single-threaded reference" % (n, frames, substeps, sec)}
@@ -107,8 +114,8 @@ def run_contacts_sharded(args, capi, kind, rank, local_rank, world_size):
     result = None
     if rank == 0:
         result = {
-            "metric": "body*substeps/sec at 262k rigid bodies, 20 substeps/frame",
-            "value": total * args.substeps * args.steps / wall, "unit": "body*substeps/s", "n_gpus": world_size,
+            "metric": METRIC,
+            "value": total * args.substeps * args.steps / wall, "unit": "body\u00b7substeps/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "EXTENSION body-body contacts: %d unit boxes per GPU x %d substeps/frame, scene '%s'"
@@ -251,9 +258,9 @@ def main():
             key = "%s_%d" % (args.mode, count)
             traffic = json.load(open(tfile)).get(key, {}).get("bytes_per_launch")
         result = {
-            "metric": "body*substeps/sec at 262k rigid bodies, 20 substeps/frame",
+            "metric": METRIC,
             "value": total * args.substeps * args.steps / wall,
-            "unit": "body*substeps/s",
+            "unit": "body\u00b7substeps/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -314,7 +321,7 @@ def main():
                 world.step(FRAME_TIME, args.substeps)
                 state = world.download()
             per_frame = (time.perf_counter() - t0) / 3
-            result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": "body*substeps/s",
+            result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": "body\u00b7substeps/s",
                                         "ms_per_frame": per_frame * 1e3,
                                         "what": "pageable host AoS upload + step + download every frame"}
             # What the reference's app actually needs per frame: state stays resident, only Rigid::frame() of every
@@ -324,7 +331,7 @@ def main():
                 world.step(FRAME_TIME, args.substeps)
                 world.frames()
             per_frame = (time.perf_counter() - t0) / 5
-            result["render_readback"] = {"value": count * args.substeps / per_frame, "unit": "body*substeps/s",
+            result["render_readback"] = {"value": count * args.substeps / per_frame, "unit": "body\u00b7substeps/s",
                                          "ms_per_frame": per_frame * 1e3,
                                          "what": "step + download of Rigid::frame() (56 B/body) every frame"}
         if world_size == 1 and not args.no_cpu_baseline and mode != capi.MODE_CONTACTS:
