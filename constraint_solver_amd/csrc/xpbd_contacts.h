@@ -39,7 +39,7 @@ struct ContactBuffers {
     double *frame_p1;       // [7][stride] post-integrate frame: origin xyz, rotation s x y z
     double *frame_past;     // [7][stride] frame before integrate
     double *past_pos;       // [3][stride] position before integrate (for derive)
-    Manifold *manifolds;    // [n_pairs]
+    ContactManifold *manifolds; // [n_pairs]
     unsigned long long *stats; // [2] touching pairs, manifold points (summed over substeps)
     uint32_t *scan_scratch; // block totals of the scans
     // joints: CSR body -> incident joints (ascending joint index); joint_off is NULL when there are none

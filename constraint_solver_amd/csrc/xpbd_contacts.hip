@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
     Quat drot{0.0, 0.0, 0.0, 0.0};
     uint32_t count = 0;
     for (uint32_t k = c.nbr_off[i]; k < c.nbr_off[i + 1]; ++k) {
-        const Manifold *m = c.manifolds + c.nbr_pair[k];
+        const ContactManifold *m = c.manifolds + c.nbr_pair[k];
         const uint32_t n_points = m->n_points;
         if (n_points == 0)
             continue;
@@ -534,8 +534,8 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         const bool ref_is_a = m->feature != 1u;
         const bool self_is_inc = self_is_a != ref_is_a;
         for (uint32_t pt = 0; pt < n_points; ++pt) {
-            const Vec3 p_inc{m->p_inc[pt][0], m->p_inc[pt][1], m->p_inc[pt][2]};
-            const Vec3 p_ref{m->p_ref[pt][0], m->p_ref[pt][1], m->p_ref[pt][2]};
+            const Vec3 p_inc{m->point[pt][0][0], m->point[pt][0][1], m->point[pt][0][2]};
+            const Vec3 p_ref{m->point[pt][1][0], m->point[pt][1][1], m->point[pt][1][2]};
             const Vec3 p_self = self_is_inc ? p_inc : p_ref, p_other = self_is_inc ? p_ref : p_inc;
             const Vec3 correction = p_ref - p_inc;
             const Vec3 moved_self = frame_delta(self.p1, self.past, p_self), moved_other = frame_delta(other.p1, other.past, p_other);
@@ -701,7 +701,7 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
                                     uint32_t n_pairs, SatScratch *list, hipStream_t stream)
 {
-    return launch_sat_pairs(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, c.stats, true, list, stream);
+    return launch_sat_contacts(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, c.stats, list, stream);
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,

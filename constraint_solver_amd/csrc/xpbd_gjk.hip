@@ -226,7 +226,7 @@ __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const M
 template <uint32_t L, bool PRETEST>
 __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                  GjkResult *__restrict__ out, Manifold *__restrict__ manifolds,
+                                                  GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds,
                                                   uint32_t *__restrict__ hit_count, uint32_t *__restrict__ hits,
                                                   unsigned long long *__restrict__ seeds)
 {
@@ -347,14 +347,14 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
 // EPA of one penetrating pair by one wave; the polytope starts from the simplex k_gjk_pairs left.
 __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
-                                         GjkResult *__restrict__ out, Manifold *__restrict__ manifolds, uint32_t lane)
+                                         GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint32_t lane)
 {
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
     const ShapeDesc da = t.desc[b.shape_id[ia]], db = t.desc[b.shape_id[ib]];
     const uint32_t na = da.n_verts, nb = db.n_verts;
     GjkResult *r = out ? out + p : nullptr;
-    Manifold *mf = manifolds ? manifolds + p : nullptr;
+    ContactManifold *mf = manifolds ? manifolds + p : nullptr;
     uint32_t epa_iters = 0;
     auto finish = [&](int32_t st) {
         if (lane == 0) {
@@ -505,8 +505,8 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
             mf->feature = 2; // reference body A, incident body B
             mf->index_a = mf->index_b = 0;
             mf->separation = -best_dist;
-            mf->p_ref[0][0] = pa.x, mf->p_ref[0][1] = pa.y, mf->p_ref[0][2] = pa.z;
-            mf->p_inc[0][0] = pb.x, mf->p_inc[0][1] = pb.y, mf->p_inc[0][2] = pb.z;
+            mf->point[0][1][0] = pa.x, mf->point[0][1][1] = pa.y, mf->point[0][1][2] = pa.z; // on the reference body A
+            mf->point[0][0][0] = pb.x, mf->point[0][0][1] = pb.y, mf->point[0][0][2] = pb.z; // on the incident body B
         }
     }
     finish(1);
@@ -516,7 +516,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 // counter the NEXT k_gjk_pairs launch appends through (the two counters alternate, see GjkScratch).
 __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
-                                                  Manifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_count,
+                                                  ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_count,
                                                   uint32_t *__restrict__ next_hit_count, const uint32_t *__restrict__ hits,
                                                   const unsigned long long *__restrict__ seeds)
 {
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
 size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 12 + 8; }
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                                uint32_t n_pairs, GjkResult *out, Manifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
+                                uint32_t n_pairs, GjkResult *out, ContactManifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
                                 hipStream_t stream)
 {
     if (n_pairs == 0)

@@ -52,8 +52,21 @@ struct Manifold {
 
 // pairs[2*p], pairs[2*p+1] are body indices (A, B); 16, 32 or 64 lanes per pair.  frames: [7][stride] object->world
 // frames of all bodies (origin xyz, rotation s x y z).  stats (optional): [0] += touching pairs, [1] += points.
+// The same result as the contact pipeline stores it: points interleaved (incident, reference) so that the usual
+// manifold of <= 4 points is the first 208 bytes, records 512-byte aligned -- the pair solve reads every manifold
+// twice, and with the 408-byte public layout (p_ref block, then p_inc block, unaligned) a 4-point manifold touched
+// four 128-byte lines per read: PMC showed 346 MB fetched per launch against ~210 MB needed.
+struct alignas(512) ContactManifold {
+    uint32_t n_points;
+    uint32_t feature;
+    uint32_t index_a, index_b;
+    double separation;
+    double point[kMaxManifoldPoints][2][3]; // [k][0] = on the incident body, [k][1] = on the reference body
+};
+static_assert(sizeof(ContactManifold) == 512, "one contact manifold = four cache lines, the first two hold <= 4 points");
+
 // Block-reduced statistics of a manifold array: stats[0] += touching pairs, stats[1] += contact points.
-hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream);
+hipError_t launch_manifold_stats(const ContactManifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream);
 
 // Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two uint32, zero when
 // idle; launch k appends through counters[k & 1] and its SAT kernel zeroes counters[(k + 1) & 1] for the next launch
@@ -64,12 +77,14 @@ struct SatScratch {
     uint32_t calls;
 };
 
-// sphere_pretest: answer "no contact" for pairs whose tight bounding spheres are disjoint (the contact pipeline's
-// semantics; the diagnostic entry point xpbd_world_narrowphase runs the full query on every pair).  With `list` the
-// pre-test runs as a pass of its own and the SAT only over the surviving pairs -- same results, worth it when most
-// pairs fail the test (a scene of loose bodies), a few per cent slower when most pass (stacks).
+// The contact pipeline answers "no contact" for pairs whose tight bounding spheres are disjoint (the diagnostic entry
+// point xpbd_world_narrowphase runs the full query on every pair).  With `list` the pre-test runs as a pass of its own
+// and the SAT only over the surviving pairs -- same results, worth it when most pairs fail the test (a scene of loose
+// bodies), a few per cent slower when most pass (stacks).
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, bool sphere_pretest, SatScratch *list,
-                            hipStream_t stream);
+                            uint32_t n_pairs, Manifold *out, hipStream_t stream); // diagnostic: every pair, full query
+hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                               uint32_t n_pairs, ContactManifold *out, unsigned long long *stats, SatScratch *list,
+                               hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form
 
 } // namespace xpbd

@@ -18,6 +18,8 @@
 // survive the parallel order.  Clipping runs one polygon vertex per lane with wave prefix sums.
 #include <cfloat>
 
+#include <type_traits>
+
 #include "xpbd_device.hpp"
 #include "xpbd_pairs.h"
 
@@ -116,9 +118,21 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 // width and all shuffles stay inside the group, so every instantiation produces the same bits.  The block is ONE
 // wave, hence __syncthreads() is a wave-local fence and the groups of a wave may diverge freely (one pair separated,
 // the next one clipping).
-template <uint32_t L, class Lds>
+// One contact point into either result layout.
+__device__ __forceinline__ void set_point(Manifold &m, uint32_t k, Vec3 inc, Vec3 ref)
+{
+    m.p_inc[k][0] = inc.x, m.p_inc[k][1] = inc.y, m.p_inc[k][2] = inc.z;
+    m.p_ref[k][0] = ref.x, m.p_ref[k][1] = ref.y, m.p_ref[k][2] = ref.z;
+}
+__device__ __forceinline__ void set_point(ContactManifold &m, uint32_t k, Vec3 inc, Vec3 ref)
+{
+    m.point[k][0][0] = inc.x, m.point[k][0][1] = inc.y, m.point[k][0][2] = inc.z;
+    m.point[k][1][0] = ref.x, m.point[k][1][1] = ref.y, m.point[k][1][2] = ref.z;
+}
+
+template <uint32_t L, class Lds, class M>
 __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
-                                         const uint32_t *__restrict__ pairs, uint32_t p, Manifold *__restrict__ out, uint32_t lane)
+                                         const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane)
 {
     constexpr uint32_t H = L / 2; // lanes per body in the two-sided stages
     // ---- group-uniform inputs ---------------------------------------------------------------------
@@ -128,7 +142,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
     const ShapeDesc da = t.desc[sa], db = t.desc[sb];
 
-    Manifold *m = out + p;
+    M *m = out + p;
     if (da.n_verts == 0 || db.n_verts == 0 || da.n_faces == 0 || db.n_faces == 0) {
         if (lane == 0)
             m->n_points = 0; // the reference's .unwrap() / index would panic; the extension reports "no contact"
@@ -284,8 +298,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
             m->index_a = i;
             m->index_b = j;
             m->separation = ebest;
-            m->p_ref[0][0] = pa.x, m->p_ref[0][1] = pa.y, m->p_ref[0][2] = pa.z;
-            m->p_inc[0][0] = pb.x, m->p_inc[0][1] = pb.y, m->p_inc[0][2] = pb.z;
+            set_point(*m, 0, pb, pa);
         }
         return;
     }
@@ -385,8 +398,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     if (keep && inc - 1 < kMaxManifoldPoints) {
         const uint32_t at = inc - 1;
         const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
-        m->p_inc[at][0] = pt.x, m->p_inc[at][1] = pt.y, m->p_inc[at][2] = pt.z;
-        m->p_ref[at][0] = on_ref.x, m->p_ref[at][1] = on_ref.y, m->p_ref[at][2] = on_ref.z;
+        set_point(*m, at, pt, on_ref);
     }
     if (lane != 0)
         return;
@@ -422,11 +434,11 @@ struct SatLds {
 };
 
 // One group of L lanes per pair, 64 / L pairs per wave, pairs in list order.  PRETEST: the contact pipeline's form.
-template <uint32_t L, uint32_t V, bool PRETEST>
+template <uint32_t L, uint32_t V, bool PRETEST, class M>
 __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(BodyArrays b, PolytopeTables t,
                                                                                const double *__restrict__ frames,
                                                                                const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                                               Manifold *__restrict__ out)
+                                                                               M *__restrict__ out)
 {
     using Lds = typename SatLds<L, V>::Record;
     __shared__ Lds s_all[SatLds<L, V>::PW];
@@ -449,7 +461,7 @@ constexpr uint32_t kPretestBlock = 1024;
 
 __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                                 const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                                Manifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
+                                                                ContactManifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
                                                                 uint32_t *__restrict__ survivors)
 {
     __shared__ uint32_t wave_base[kPretestBlock / 64 + 1];
@@ -489,7 +501,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
                                                                                    const uint32_t *__restrict__ survivor_count,
                                                                                    uint32_t *__restrict__ next_survivor_count,
                                                                                    const uint32_t *__restrict__ survivors,
-                                                                                   Manifold *__restrict__ out)
+                                                                                   ContactManifold *__restrict__ out)
 {
     using Lds = typename SatLds<L, V>::Record;
     __shared__ Lds s_all[SatLds<L, V>::PW];
@@ -508,7 +520,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
 // not even one per 256 pairs -- a grid-stride loop over at most kStatsBlocks blocks, one atomic pair each.
 constexpr uint32_t kStatsBlocks = 128;
 
-__global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pairs, unsigned long long *__restrict__ stats)
+__global__ void k_manifold_stats(const ContactManifold *__restrict__ m, uint32_t n_pairs, unsigned long long *__restrict__ stats)
 {
     uint32_t points = 0, touching = 0;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
@@ -534,7 +546,7 @@ __global__ void k_manifold_stats(const Manifold *__restrict__ m, uint32_t n_pair
 
 } // namespace
 
-hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream)
+hipError_t launch_manifold_stats(const ContactManifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream)
 {
     if (n_pairs && stats) {
         const uint32_t nb = (n_pairs + 255) / 256;
@@ -544,45 +556,55 @@ hipError_t launch_manifold_stats(const Manifold *m, uint32_t n_pairs, unsigned l
 }
 
 namespace {
-// kind: 0 = every pair, full query; 1 = in-group sphere pre-test; 2 = pre-test pass + survivor list
-template <uint32_t L, uint32_t V>
-void launch_sat_kernels(int kind, const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                        uint32_t n_pairs, Manifold *out, SatScratch *list, hipStream_t stream)
+// Lanes per pair and vertex capacity by the largest shape: boxes and tetrahedra (<= 8 vertices and faces) run four
+// pairs per wave with 8-vertex records; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with 16-vertex
+// records; anything larger gets a whole wave.
+template <class Launch>
+void for_shape_class(const PolytopeTables &t, Launch launch)
 {
-    const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
-    if (kind == 2) {
-        uint32_t *count = list->counters + (list->calls & 1u), *next = list->counters + ((list->calls + 1u) & 1u);
-        ++list->calls;
-        hipLaunchKernelGGL(k_pair_pretest, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
-                           frames, pairs, n_pairs, out, count, list->survivors);
-        hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, out);
-    } else if (kind == 1) {
-        hipLaunchKernelGGL((k_sat_pairs<L, V, true>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
-    } else {
-        hipLaunchKernelGGL((k_sat_pairs<L, V, false>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
-    }
+    if (t.max_verts <= 8 && t.max_faces <= 8)
+        launch(std::integral_constant<uint32_t, 16>{}, std::integral_constant<uint32_t, 8>{});
+    else if (t.max_verts <= 16)
+        launch(std::integral_constant<uint32_t, XPBD_SAT_MID_LANES>{}, std::integral_constant<uint32_t, 16>{});
+    else
+        launch(std::integral_constant<uint32_t, 64>{}, std::integral_constant<uint32_t, kMaxV>{});
 }
 } // namespace
 
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                            uint32_t n_pairs, Manifold *out, unsigned long long *stats, bool sphere_pretest, SatScratch *list,
-                            hipStream_t stream)
+                            uint32_t n_pairs, Manifold *out, hipStream_t stream)
 {
-    if (n_pairs) {
-        const int kind = !sphere_pretest ? 0 : (list ? 2 : 1);
-        // lanes per pair and vertex capacity by the largest shape: boxes and tetrahedra (<= 8 vertices and faces) run
-        // four pairs per wave with 8-vertex records; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
-        // 16-vertex records; anything larger gets a whole wave
-        if (t.max_verts <= 8 && t.max_faces <= 8)
-            launch_sat_kernels<16, 8>(kind, b, t, frames, pairs, n_pairs, out, list, stream);
-        else if (t.max_verts <= 16)
-            launch_sat_kernels<XPBD_SAT_MID_LANES, 16>(kind, b, t, frames, pairs, n_pairs, out, list, stream);
-        else
-            launch_sat_kernels<64, kMaxV>(kind, b, t, frames, pairs, n_pairs, out, list, stream);
-        if (stats) {
-            const uint32_t nb = (n_pairs + 255) / 256;
-            hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);
+    if (n_pairs)
+        for_shape_class(t, [&](auto lanes, auto verts) {
+            constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
+            hipLaunchKernelGGL((k_sat_pairs<L, V, false, Manifold>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
+                               frames, pairs, n_pairs, out);
+        });
+    return hipGetLastError();
+}
+
+hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                               uint32_t n_pairs, ContactManifold *out, unsigned long long *stats, SatScratch *list,
+                               hipStream_t stream)
+{
+    if (n_pairs == 0)
+        return hipSuccess;
+    for_shape_class(t, [&](auto lanes, auto verts) {
+        constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
+        const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
+        if (list) { // pre-test pass, then the SAT over the survivors
+            uint32_t *count = list->counters + (list->calls & 1u), *next = list->counters + ((list->calls + 1u) & 1u);
+            ++list->calls;
+            hipLaunchKernelGGL(k_pair_pretest, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
+                               frames, pairs, n_pairs, out, count, list->survivors);
+            hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, out);
+        } else {
+            hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         }
+    });
+    if (stats) {
+        const uint32_t nb = (n_pairs + 255) / 256;
+        hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);
     }
     return hipGetLastError();
 }

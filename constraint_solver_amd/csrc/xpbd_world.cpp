@@ -159,7 +159,7 @@ struct xpbd_world {
         c.frame_p1 = cb_frame_p1.as<double>();
         c.frame_past = cb_frame_past.as<double>();
         c.past_pos = cb_past_pos.as<double>();
-        c.manifolds = cb_manifolds.as<xpbd::Manifold>();
+        c.manifolds = cb_manifolds.as<xpbd::ContactManifold>();
         c.stats = cb_stats.as<unsigned long long>();
         c.scan_scratch = cb_scan.as<uint32_t>();
         c.joints = n_joints ? jt_joints.as<xpbd::Joint>() : nullptr;
@@ -276,7 +276,7 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_nbr.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_nbr_pair.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_pairs.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 8));
-    XPBD_HIP_TRY(w->cb_manifolds.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * sizeof(xpbd::Manifold)));
+    XPBD_HIP_TRY(w->cb_manifolds.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * sizeof(xpbd::ContactManifold)));
     c = w->contact_buffers();
     XPBD_HIP_TRY(xpbd::launch_neighbour_fill(b, c, w->stream));
     w->have_neighbours = true;
@@ -587,7 +587,7 @@ int xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pair
     XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * w->stride * 8));
     XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
     XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(), w->pair_buf.as<uint32_t>(),
-                                        n_pairs, w->manifold_buf.as<xpbd::Manifold>(), nullptr, false, nullptr, w->stream));
+                                        n_pairs, w->manifold_buf.as<xpbd::Manifold>(), w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::Manifold),
                                 hipMemcpyDeviceToHost, w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
