@@ -223,9 +223,13 @@ __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const M
 // Boolean GJK, L lanes per pair.  out / manifolds (each optional) receive the verdict of every pair that is NOT
 // penetrating; a penetrating pair goes to the hit list with its simplex and is finished by k_epa_pairs.
 // PRETEST (contact pipeline only): as in k_sat_pairs, disjoint tight bounding spheres mean "separated" at once.
+// With `survivors` (the two-pass form, after k_pair_pretest of xpbd_pairs.hip) the groups take their pairs from that
+// list, n_pairs is read from *survivor_count, and block 0 zeroes the counter of the next launch.
 template <uint32_t L, bool PRETEST>
 __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
+                                                  const uint32_t *__restrict__ survivors, const uint32_t *__restrict__ survivor_count,
+                                                  uint32_t *__restrict__ next_survivor_count,
                                                   GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds,
                                                   uint32_t *__restrict__ hit_count, uint32_t *__restrict__ hits,
                                                   unsigned long long *__restrict__ seeds)
@@ -233,9 +237,15 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     constexpr uint32_t PW = 64 / L; // pairs per wave
     __shared__ GjkVerts s_all[PW];
     GjkVerts &s = s_all[threadIdx.x / L];
-    const uint32_t p = blockIdx.x * PW + threadIdx.x / L;
+    const uint32_t slot = blockIdx.x * PW + threadIdx.x / L;
     const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
-    const bool live = p < n_pairs;
+    if (survivors) {
+        n_pairs = *survivor_count;
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            *next_survivor_count = 0;
+    }
+    const bool live = slot < n_pairs;
+    const uint32_t p = (survivors && live) ? survivors[slot] : slot;
 
     uint32_t ia = 0, ib = 0, sa = 0, sb = 0;
     ShapeDesc da{}, db{};
@@ -537,7 +547,7 @@ size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 12 + 8; }
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                 uint32_t n_pairs, GjkResult *out, ContactManifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
-                                hipStream_t stream)
+                                SatScratch *list, hipStream_t stream)
 {
     if (n_pairs == 0)
         return hipSuccess;
@@ -546,14 +556,26 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     uint32_t *count = scratch.counters + (scratch.calls & 1u), *next = scratch.counters + ((scratch.calls + 1u) & 1u);
     ++scratch.calls;
     const dim3 grid16((n_pairs + 3) / 4), grid32((n_pairs + 1) / 2);
+    const uint32_t *survivors = nullptr;
+    uint32_t *survivor_count = nullptr, *next_survivor_count = nullptr;
+    if (sphere_pretest && list && manifolds) { // two-pass form: the pre-test pass answers the rejected pairs
+        if (hipError_t e = launch_pair_pretest(b, t, frames, pairs, n_pairs, manifolds, *list, &survivor_count, &next_survivor_count, stream))
+            return e;
+        survivors = list->survivors;
+        sphere_pretest = false; // the survivors have passed it
+    }
     if (t.max_verts <= 16 && sphere_pretest) // 16 lanes per pair, four pairs per wave
-        hipLaunchKernelGGL((k_gjk_pairs<16, true>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
+        hipLaunchKernelGGL((k_gjk_pairs<16, true>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
+                           next_survivor_count, out, manifolds, count, hits, seeds);
     else if (t.max_verts <= 16)
-        hipLaunchKernelGGL((k_gjk_pairs<16, false>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
+        hipLaunchKernelGGL((k_gjk_pairs<16, false>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
+                           next_survivor_count, out, manifolds, count, hits, seeds);
     else if (sphere_pretest)
-        hipLaunchKernelGGL((k_gjk_pairs<32, true>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
+        hipLaunchKernelGGL((k_gjk_pairs<32, true>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
+                           next_survivor_count, out, manifolds, count, hits, seeds);
     else
-        hipLaunchKernelGGL((k_gjk_pairs<32, false>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, manifolds, count, hits, seeds);
+        hipLaunchKernelGGL((k_gjk_pairs<32, false>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
+                           next_survivor_count, out, manifolds, count, hits, seeds);
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
     hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, next, hits,
                        seeds);

@@ -83,6 +83,11 @@ struct SatScratch {
 // bodies), a few per cent slower when most pass (stacks).
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                             uint32_t n_pairs, Manifold *out, hipStream_t stream); // diagnostic: every pair, full query
+// The pre-test pass alone: answers the rejected pairs in `out`, appends the others to list.survivors and returns the
+// counter this launch appends through and the one the consumer kernel must zero for the next launch.
+hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                               uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
+                               hipStream_t stream);
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, unsigned long long *stats, SatScratch *list,
                                hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form

@@ -583,6 +583,18 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
     return hipGetLastError();
 }
 
+hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                               uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
+                               hipStream_t stream)
+{
+    *count = list.counters + (list.calls & 1u);
+    *next_count = list.counters + ((list.calls + 1u) & 1u);
+    ++list.calls;
+    hipLaunchKernelGGL(k_pair_pretest, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
+                       pairs, n_pairs, out, *count, list.survivors);
+    return hipGetLastError();
+}
+
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, unsigned long long *stats, SatScratch *list,
                                hipStream_t stream)
@@ -593,10 +605,8 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
         const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
         if (list) { // pre-test pass, then the SAT over the survivors
-            uint32_t *count = list->counters + (list->calls & 1u), *next = list->counters + ((list->calls + 1u) & 1u);
-            ++list->calls;
-            hipLaunchKernelGGL(k_pair_pretest, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
-                               frames, pairs, n_pairs, out, count, list->survivors);
+            uint32_t *count = nullptr, *next = nullptr;
+            (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, out, *list, &count, &next, stream);
             hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, out);
         } else {
             hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);

@@ -293,7 +293,7 @@ int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_ro
         if (int rc = ensure_gjk_scratch(w, w->n_pairs))
             return rc;
         XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds,
-                                                w->gjk_scratch, true, w->stream));
+                                                w->gjk_scratch, true, w->sat_two_pass ? &w->sat_scratch : nullptr, w->stream));
         XPBD_HIP_TRY(xpbd::launch_manifold_stats(c.manifolds, w->n_pairs, c.stats, w->stream));
     } else {
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
@@ -844,7 +844,7 @@ int xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_
         return rc;
     XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(),
                                             w->pair_buf.as<uint32_t>(), n_pairs, w->manifold_buf.as<xpbd::GjkResult>(),
-                                            nullptr, w->gjk_scratch, false, w->stream));
+                                            nullptr, w->gjk_scratch, false, nullptr, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::GjkResult), hipMemcpyDeviceToHost,
                                 w->stream));
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));

@@ -219,9 +219,9 @@ int  xpbd_world_set_narrowphase(xpbd_world *w, uint32_t narrowphase);
  * vertex distance): the neighbour lists are built once per step call from spheres inflated by a whole frame of
  * travel, so in a given substep most pairs of a loose scene cannot touch, and those are answered "no contact"
  * without running the query.  (xpbd_world_narrowphase / _gjk, the diagnostic entry points, always run it.)
- * The SAT can do this inside its kernel (ONE_PASS) or as a pass of its own followed by the SAT over the surviving
- * pairs only (TWO_PASS): identical results, different cost -- AUTO picks per step call from the share of touching
- * pairs in the previous one. */
+ * The test can run inside the narrowphase kernel (ONE_PASS) or as a pass of its own followed by the SAT / the GJK
+ * over the surviving pairs only (TWO_PASS): identical results, different cost -- AUTO picks per step call from the
+ * share of touching pairs in the previous one. */
 #define XPBD_SAT_SCHEDULE_AUTO     0u
 #define XPBD_SAT_SCHEDULE_ONE_PASS 1u
 #define XPBD_SAT_SCHEDULE_TWO_PASS 2u

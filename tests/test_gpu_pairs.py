@@ -536,7 +536,7 @@ def test_narrowphases_on_random_convex_hulls():
 def test_contact_pipeline_on_random_hulls_with_whole_wave_groups(narrowphase):
     """Shapes above 16 vertices select the widest kernels (64 lanes per pair for the SAT with 32-vertex records, 32
     lanes for the boolean GJK): a pile of random 18-, 16- and 10-vertex hulls through the whole pipeline, under every
-    SAT schedule, against the oracle."""
+    pre-test schedule, against the oracle."""
     import hull_util as hu
     raw = [hu.random_hull(7, 18, 0.6), hu.random_hull(8, 16, 0.5), hu.random_hull(9, 10, 0.4)]
     polys = (ob.Polytope * 3)(*[hu.as_oracle(*h) for h in raw])
@@ -551,7 +551,7 @@ def test_contact_pipeline_on_random_hulls_with_whole_wave_groups(narrowphase):
     want = bodies
     for _ in range(6):
         want = ob.contacts_step_joints(want, sid, polys, np.zeros(0, dtype=capi.JOINT_DTYPE), DT, 8, 0.02, narrowphase=int(narrowphase))
-    schedules = (capi.SAT_SCHEDULE_ONE_PASS, capi.SAT_SCHEDULE_TWO_PASS) if narrowphase == capi.NARROWPHASE_SAT else (capi.SAT_SCHEDULE_AUTO,)
+    schedules = (capi.SAT_SCHEDULE_ONE_PASS, capi.SAT_SCHEDULE_TWO_PASS, capi.SAT_SCHEDULE_AUTO)
     touched = 0
     for schedule in schedules:
         with capi.World(mode=capi.MODE_CONTACTS) as w:
