@@ -1,4 +1,4 @@
-// xpbd_pairs.hip -- body-body contact EXTENSION: wave-per-pair SAT narrowphase for gfx950.
+// xpbd_pairs.hip -- body-body contact EXTENSION: SAT narrowphase for gfx950, one group of 16 / 32 / 64 lanes per pair.
 //
 // The reference stops after the A-face query of `sat` (src/collision.rs:37-121, an uncalled
 // stub); this finishes the commented-out sketch there.  Parity is UNPINNED (no reference result
@@ -11,11 +11,13 @@
 //   feature choice        src/collision.rs:47-59,89-92 (comments there)
 //   reference plane / incident face  src/collision.rs:66, 76-85 (first minimum of n . n_ref)
 //
-// Mapping: ONE WAVE = ONE CANDIDATE PAIR.  Both bodies' vertices are transformed once into LDS
-// (world space, and each into the other's local space); lanes then run in parallel over
-// faces x vertices, over the pairs of unique edge directions and over the incident body's faces, and combine
-// with __shfl_xor reductions that carry (value, index) so the reference's first/last tie-breaks
-// survive the parallel order.  Clipping runs one polygon vertex per lane with wave prefix sums.
+// Mapping: ONE GROUP OF LANES = ONE CANDIDATE PAIR (sat_pair below; 4, 2 or 1 pairs per wave by the largest shape).
+// Both bodies' vertices are transformed once into LDS (world space, and each into the other's local space); the
+// lanes of the group then run in parallel over faces x vertices, over the pairs of unique edge directions and over the
+// incident body's faces, and combine with __shfl_xor reductions that carry (value, index) so the reference's
+// first/last tie-breaks survive the parallel order.  Clipping runs one polygon vertex per lane with prefix sums.
+// Kernels: k_sat_pairs (every listed pair; optionally with the contact pipeline's tight-sphere pre-test),
+// k_pair_pretest + k_sat_survivors (the pre-test as a pass of its own, the SAT over the survivors only).
 #include <cfloat>
 
 #include <type_traits>
