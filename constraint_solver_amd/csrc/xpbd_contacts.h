@@ -68,6 +68,14 @@ hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
                                     hipStream_t stream);
 
+// launch_pair_solve_derive of this substep and launch_integrate_ground of the next one in a single kernel: the new
+// state goes to dyn_out, the next substep's frames to the next_* arrays (a second set: the frames in `c` are still
+// being read by the other bodies).
+hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double *dyn_out, double h,
+                                              const ContactBuffers &c, double *next_frame_p1, double *next_frame_past,
+                                              double *next_past_pos, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
+                                              hipStream_t stream);
+
 // Frames of all bodies from the SoA state into a [7][stride] array (used by the diagnostic narrowphase).
 hipError_t launch_body_frames(const BodyArrays &b, double *frames, hipStream_t stream);
 // ... and body-major, frames[7 * i + f], for the host read-back.

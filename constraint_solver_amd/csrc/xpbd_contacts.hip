@@ -506,15 +506,12 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
     return p.inv_mass + dot(p.inv_inertia * angular_impulse, angular_impulse);
 }
 
-__global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
-                                                              ContactBuffers c)
+// Jacobi pair solve + joints + derive of body i: its state at the end of the substep.
+__device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i, double h,
+                                                              const PairBody &self)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
-        return;
     const uint32_t st = b.stride;
     const double compliance = 1e-6 / (h * h);
-    const PairBody self = load_pair_body(b, c, i);
 
     Vec3 dpos{0.0, 0.0, 0.0};
     Quat drot{0.0, 0.0, 0.0, 0.0};
@@ -595,7 +592,65 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         d.rot = normalized(self.rot + Quat{drot.s / cnt, drot.x / cnt, drot.y / cnt, drot.z / cnt});
     }
     derive_body(d, load3(c.past_pos, 0, st, i), self.past.rotation, h);
+    return d;
+}
+
+__global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
+                                                                                        ContactBuffers c)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const PairBody self = load_pair_body(b, c, i);
+    store_dynamic(dyn_out, b.stride, i, pair_solve_derive_body(b, c, i, h, self));
+}
+
+// The end of substep k and the beginning of substep k + 1 of one body in one kernel: pair solve + derive, then
+// integrate + ground contacts straight from registers.  Nothing a body needs from the others changes in between
+// (they read each other's state of substep k: dyn and the frames of `c`), so the new state goes to the other dyn
+// buffer and the frames of substep k + 1 to the other frame set (`next`).  Saves the store + reload of the dynamic
+// state, half of the static loads and one launch per substep; same arithmetic, same bits.  Only for step calls
+// that run all their substeps on one device: a halo exchange sits exactly at this seam.
+template <bool TRACE>
+__global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_integrate_ground(
+    BodyArrays b, ShapeTable shapes, double *__restrict__ dyn_out, double h, ContactBuffers c, double *__restrict__ next_frame_p1,
+    double *__restrict__ next_frame_past, double *__restrict__ next_past_pos, uint32_t *__restrict__ last_mask,
+    uint32_t *__restrict__ trace_masks, uint32_t trace_row)
+{
+    extern __shared__ double lds[]; // shape vertex tables, as in k_integrate_ground
+    uint32_t *lds_off = reinterpret_cast<uint32_t *>(lds + 3 * shapes.total_verts);
+    for (uint32_t k = threadIdx.x; k < 3 * shapes.total_verts; k += blockDim.x)
+        lds[k] = shapes.verts[k];
+    for (uint32_t k = threadIdx.x; k <= shapes.n_shapes; k += blockDim.x)
+        lds_off[k] = shapes.offsets[k];
+    __syncthreads();
+
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t st = b.stride;
+    BodyDynamic d;
+    {
+        const PairBody self = load_pair_body(b, c, i);
+        d = pair_solve_derive_body(b, c, i, h, self);
+    }
+    const Vec3 derived_vel = d.vel, derived_ang = d.ang; // what memory holds between substeps (k_integrate_ground keeps
+                                                          // its integrated velocities in registers only)
+    const BodyStatic s = load_static(b, i);
+    const uint32_t sid = b.shape_id[i];
+    const uint32_t v0 = lds_off[sid];
+    const double compliance = 1e-6 / (h * h);
+    const SubstepFrames f = integrate_body(d, s, h);
+    store_frame(next_frame_past, st, i, f.past);
+    store_frame(next_frame_p1, st, i, f.cur);
+    store3(next_past_pos, 0, st, i, f.past_pos);
+    const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
+    d.vel = derived_vel;
+    d.ang = derived_ang;
     store_dynamic(dyn_out, st, i, d);
+    last_mask[i] = mask;
+    if (TRACE)
+        trace_masks[(size_t)trace_row * st + i] = mask;
 }
 
 // Halo exchange: one lane per (body, field); the buffer side is contiguous, the SoA side is a gather.
@@ -709,6 +764,23 @@ hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double
 {
     if (b.n)
         hipLaunchKernelGGL(k_pair_solve_derive, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double *dyn_out, double h,
+                                              const ContactBuffers &c, double *next_frame_p1, double *next_frame_past,
+                                              double *next_past_pos, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
+                                              hipStream_t stream)
+{
+    if (b.n == 0)
+        return hipSuccess;
+    const size_t lds_bytes = (size_t)s.total_verts * 3 * sizeof(double) + (size_t)(s.n_shapes + 1) * sizeof(uint32_t);
+    if (trace_masks)
+        hipLaunchKernelGGL(k_pair_solve_integrate_ground<true>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, dyn_out, h, c,
+                           next_frame_p1, next_frame_past, next_past_pos, last_mask, trace_masks, trace_row);
+    else
+        hipLaunchKernelGGL(k_pair_solve_integrate_ground<false>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, dyn_out, h, c,
+                           next_frame_p1, next_frame_past, next_past_pos, last_mask, trace_masks, trace_row);
     return hipGetLastError();
 }
 

@@ -118,6 +118,8 @@ struct xpbd_world {
     DeviceBuffer dyn_alt, cb_centers, cb_radius, cb_cell, cb_key, cb_maxr, cb_bucket_start, cb_bucket_cursor, cb_items,
         cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_frame_p1, cb_frame_past,
         cb_past_pos, cb_manifolds, cb_stats, cb_scan, cb_slot_sphere, cb_slot_cell;
+    // second set of per-substep frames for the fused "end of substep k + start of substep k + 1" kernel (step_contacts)
+    DeviceBuffer cb_frame_p1_b, cb_frame_past_b, cb_past_pos_b;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
@@ -136,7 +138,8 @@ struct xpbd_world {
     unsigned long long stats_touching_seen = 0, stats_pair_substeps = 0, stats_pair_substeps_seen = 0;
     DeviceBuffer gjk_counters, gjk_pairs_scratch;   // hit list of the two-kernel GJK/EPA narrowphase (xpbd_gjk.h)
     xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0};
-    xpbd::ContactBuffers contact_buffers() const
+    // frame_set: which of the two frame sets the substep reads (always 0 outside step_contacts)
+    xpbd::ContactBuffers contact_buffers(uint32_t frame_set = 0) const
     {
         xpbd::ContactBuffers c{};
         c.centers = cb_centers.as<double>();
@@ -156,9 +159,9 @@ struct xpbd_world {
         c.nbr = cb_nbr.as<uint32_t>();
         c.nbr_pair = cb_nbr_pair.as<uint32_t>();
         c.pairs = cb_pairs.as<uint32_t>();
-        c.frame_p1 = cb_frame_p1.as<double>();
-        c.frame_past = cb_frame_past.as<double>();
-        c.past_pos = cb_past_pos.as<double>();
+        c.frame_p1 = (frame_set ? cb_frame_p1_b : cb_frame_p1).as<double>();
+        c.frame_past = (frame_set ? cb_frame_past_b : cb_frame_past).as<double>();
+        c.past_pos = (frame_set ? cb_past_pos_b : cb_past_pos).as<double>();
         c.manifolds = cb_manifolds.as<xpbd::ContactManifold>();
         c.stats = cb_stats.as<unsigned long long>();
         c.scan_scratch = cb_scan.as<uint32_t>();
@@ -231,6 +234,9 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * st * 8));
     XPBD_HIP_TRY(w->cb_frame_past.reserve((size_t)7 * st * 8));
     XPBD_HIP_TRY(w->cb_past_pos.reserve((size_t)3 * st * 8));
+    XPBD_HIP_TRY(w->cb_frame_p1_b.reserve((size_t)7 * st * 8));
+    XPBD_HIP_TRY(w->cb_frame_past_b.reserve((size_t)7 * st * 8));
+    XPBD_HIP_TRY(w->cb_past_pos_b.reserve((size_t)3 * st * 8));
     XPBD_HIP_TRY(w->cb_scan.reserve(((size_t)(w->table_size > st ? w->table_size : st) / 1024 + 8) * 4));
     if (!w->cb_stats.ptr) {
         XPBD_HIP_TRY(w->cb_stats.reserve(16));
@@ -283,12 +289,9 @@ int build_neighbours(xpbd_world *w, double dt)
     return XPBD_OK;
 }
 
-// One substep of the contact pipeline (neighbour lists must be current).
-int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_row)
+// Narrowphase of the current substep on the post-integrate frames of `c`.
+int narrowphase_contacts(xpbd_world *w, const xpbd::BodyArrays &b, const xpbd::ContactBuffers &c)
 {
-    const xpbd::BodyArrays b = w->arrays();
-    const xpbd::ContactBuffers c = w->contact_buffers();
-    XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, trace_row, w->stream));
     if (w->narrowphase == XPBD_NARROWPHASE_GJK_EPA) {
         if (int rc = ensure_gjk_scratch(w, w->n_pairs))
             return rc;
@@ -299,22 +302,52 @@ int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_ro
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
                                                     w->stream));
     }
-    XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
-    std::swap(w->dyn, w->dyn_alt);
     w->stats_pair_substeps += w->n_pairs;
     return XPBD_OK;
 }
 
-// One xpbd_world_step in XPBD_MODE_CONTACTS (semantics: oracle/xpbd_pairs_oracle.h).
+// One substep of the contact pipeline (neighbour lists must be current): the form the split API
+// (xpbd_world_contacts_substep) exposes, with a seam for the halo exchange after it.
+int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_row)
+{
+    const xpbd::BodyArrays b = w->arrays();
+    const xpbd::ContactBuffers c = w->contact_buffers();
+    XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, trace_row, w->stream));
+    if (int rc = narrowphase_contacts(w, b, c))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
+    std::swap(w->dyn, w->dyn_alt);
+    return XPBD_OK;
+}
+
+// One xpbd_world_step in XPBD_MODE_CONTACTS (semantics: oracle/xpbd_pairs_oracle.h).  All substeps run here, so the
+// pair solve of substep k and the integrate + ground stage of substep k + 1 are one kernel; the frames alternate
+// between two sets because the bodies still read each other's frames of substep k while those of k + 1 are written.
 int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_t *trace)
 {
     if (!w->has_topology)
         return fail(XPBD_E_INVALID, "XPBD_MODE_CONTACTS needs xpbd_world_set_polytopes");
     if (int rc = build_neighbours(w, dt))
         return rc;
-    for (uint32_t k = 0; k < substeps; ++k)
-        if (int rc = substep_contacts(w, h, trace, k))
+    if (substeps == 0)
+        return XPBD_OK;
+    XPBD_HIP_TRY(xpbd::launch_integrate_ground(w->arrays(), w->shapes(), h, w->contact_buffers(0), w->last_mask.as<uint32_t>(), trace, 0,
+                                               w->stream));
+    for (uint32_t k = 0; k < substeps; ++k) {
+        const xpbd::BodyArrays b = w->arrays();
+        const xpbd::ContactBuffers c = w->contact_buffers(k & 1u);
+        if (int rc = narrowphase_contacts(w, b, c))
             return rc;
+        if (k + 1 < substeps) {
+            const xpbd::ContactBuffers next = w->contact_buffers((k + 1u) & 1u);
+            XPBD_HIP_TRY(xpbd::launch_pair_solve_integrate_ground(b, w->shapes(), w->dyn_alt.as<double>(), h, c, next.frame_p1,
+                                                                  next.frame_past, next.past_pos, w->last_mask.as<uint32_t>(), trace,
+                                                                  k + 1, w->stream));
+        } else {
+            XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
+        }
+        std::swap(w->dyn, w->dyn_alt);
+    }
     return XPBD_OK;
 }
 
@@ -411,7 +444,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
-                            &w->sat_counters, &w->sat_survivors})
+                            &w->sat_counters, &w->sat_survivors, &w->cb_frame_p1_b, &w->cb_frame_past_b, &w->cb_past_pos_b})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
