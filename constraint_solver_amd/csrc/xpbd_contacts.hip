@@ -507,8 +507,10 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
 }
 
 // Jacobi pair solve + joints + derive of body i: its state at the end of the substep.
+// (touching, points: += the manifolds with contact points among this body's pairs (i, j > i) and their points -- every
+// pair is counted by its smaller body, which gives the pipeline's statistics without a pass of their own)
 __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i, double h,
-                                                              const PairBody &self)
+                                                              const PairBody &self, uint32_t &touching, uint32_t &points)
 {
     const uint32_t st = b.stride;
     const double compliance = 1e-6 / (h * h);
@@ -522,6 +524,10 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
         if (n_points == 0)
             continue;
         const uint32_t j = c.nbr[k];
+        if (j > i) {
+            ++touching;
+            points += n_points;
+        }
         const PairBody other = load_pair_body(b, c, j);
         // pair (A, B) = (min, max); the reference body is A unless the reference face is on B.  The formulas are
         // written in terms of the incident and the reference body; here every term is evaluated for `self` and
@@ -595,14 +601,43 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
     return d;
 }
 
+// stats[0] += touching, stats[1] += points, summed over the workgroup: TWO atomics per workgroup (same-address atomics
+// serialise at ~10-25 ns each -- never one per pair, see xpbd_pairs.hip).  Every thread of the block must call this.
+__device__ __forceinline__ void block_add_stats(uint32_t touching, uint32_t points, unsigned long long *__restrict__ stats)
+{
+    for (uint32_t off = 32; off; off >>= 1) {
+        touching += __shfl_xor(touching, off, 64);
+        points += __shfl_xor(points, off, 64);
+    }
+    __shared__ uint32_t part[2][kBlock / 64];
+    if ((threadIdx.x & 63u) == 0) {
+        part[0][threadIdx.x >> 6] = touching;
+        part[1][threadIdx.x >> 6] = points;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0, p = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) {
+            t += part[0][w];
+            p += part[1][w];
+        }
+        if (t)
+            atomicAdd(&stats[0], (unsigned long long)t);
+        if (p)
+            atomicAdd(&stats[1], (unsigned long long)p);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
                                                                                         ContactBuffers c)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
-        return;
-    const PairBody self = load_pair_body(b, c, i);
-    store_dynamic(dyn_out, b.stride, i, pair_solve_derive_body(b, c, i, h, self));
+    uint32_t touching = 0, points = 0;
+    if (i < b.n) {
+        const PairBody self = load_pair_body(b, c, i);
+        store_dynamic(dyn_out, b.stride, i, pair_solve_derive_body(b, c, i, h, self, touching, points));
+    }
+    block_add_stats(touching, points, c.stats);
 }
 
 // The end of substep k and the beginning of substep k + 1 of one body in one kernel: pair solve + derive, then
@@ -626,31 +661,33 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
     __syncthreads();
 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
-        return;
-    const uint32_t st = b.stride;
-    BodyDynamic d;
-    {
-        const PairBody self = load_pair_body(b, c, i);
-        d = pair_solve_derive_body(b, c, i, h, self);
+    uint32_t touching = 0, points = 0;
+    if (i < b.n) {
+        const uint32_t st = b.stride;
+        BodyDynamic d;
+        {
+            const PairBody self = load_pair_body(b, c, i);
+            d = pair_solve_derive_body(b, c, i, h, self, touching, points);
+        }
+        const Vec3 derived_vel = d.vel, derived_ang = d.ang; // what memory holds between substeps (k_integrate_ground keeps
+                                                              // its integrated velocities in registers only)
+        const BodyStatic s = load_static(b, i);
+        const uint32_t sid = b.shape_id[i];
+        const uint32_t v0 = lds_off[sid];
+        const double compliance = 1e-6 / (h * h);
+        const SubstepFrames f = integrate_body(d, s, h);
+        store_frame(next_frame_past, st, i, f.past);
+        store_frame(next_frame_p1, st, i, f.cur);
+        store3(next_past_pos, 0, st, i, f.past_pos);
+        const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
+        d.vel = derived_vel;
+        d.ang = derived_ang;
+        store_dynamic(dyn_out, st, i, d);
+        last_mask[i] = mask;
+        if (TRACE)
+            trace_masks[(size_t)trace_row * st + i] = mask;
     }
-    const Vec3 derived_vel = d.vel, derived_ang = d.ang; // what memory holds between substeps (k_integrate_ground keeps
-                                                          // its integrated velocities in registers only)
-    const BodyStatic s = load_static(b, i);
-    const uint32_t sid = b.shape_id[i];
-    const uint32_t v0 = lds_off[sid];
-    const double compliance = 1e-6 / (h * h);
-    const SubstepFrames f = integrate_body(d, s, h);
-    store_frame(next_frame_past, st, i, f.past);
-    store_frame(next_frame_p1, st, i, f.cur);
-    store3(next_past_pos, 0, st, i, f.past_pos);
-    const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
-    d.vel = derived_vel;
-    d.ang = derived_ang;
-    store_dynamic(dyn_out, st, i, d);
-    last_mask[i] = mask;
-    if (TRACE)
-        trace_masks[(size_t)trace_row * st + i] = mask;
+    block_add_stats(touching, points, c.stats);
 }
 
 // Halo exchange: one lane per (body, field); the buffer side is contiguous, the SoA side is a gather.
@@ -756,7 +793,7 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
                                     uint32_t n_pairs, SatScratch *list, hipStream_t stream)
 {
-    return launch_sat_contacts(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, c.stats, list, stream);
+    return launch_sat_contacts(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, list, stream);
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,

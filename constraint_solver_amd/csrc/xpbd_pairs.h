@@ -51,7 +51,7 @@ struct Manifold {
 };
 
 // pairs[2*p], pairs[2*p+1] are body indices (A, B); 16, 32 or 64 lanes per pair.  frames: [7][stride] object->world
-// frames of all bodies (origin xyz, rotation s x y z).  stats (optional): [0] += touching pairs, [1] += points.
+// frames of all bodies (origin xyz, rotation s x y z).
 // The same result as the contact pipeline stores it: points interleaved (incident, reference) so that the usual
 // manifold of <= 4 points is the first 208 bytes, records 512-byte aligned -- the pair solve reads every manifold
 // twice, and with the 408-byte public layout (p_ref block, then p_inc block, unaligned) a 4-point manifold touched
@@ -65,8 +65,7 @@ struct alignas(512) ContactManifold {
 };
 static_assert(sizeof(ContactManifold) == 512, "one contact manifold = four cache lines, the first two hold <= 4 points");
 
-// Block-reduced statistics of a manifold array: stats[0] += touching pairs, stats[1] += contact points.
-hipError_t launch_manifold_stats(const ContactManifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream);
+// (The pipeline's statistics -- touching pairs, contact points -- are summed by the pair solve, xpbd_contacts.hip.)
 
 // Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two uint32, zero when
 // idle; launch k appends through counters[k & 1] and its SAT kernel zeroes counters[(k + 1) & 1] for the next launch
@@ -89,7 +88,7 @@ hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, con
                                uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
                                hipStream_t stream);
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, unsigned long long *stats, SatScratch *list,
+                               uint32_t n_pairs, ContactManifold *out, SatScratch *list,
                                hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form
 
 } // namespace xpbd

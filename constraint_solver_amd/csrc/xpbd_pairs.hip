@@ -517,45 +517,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
     sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[k], out, lane);
 }
 
-// stats[0] += pairs with contact points, stats[1] += contact points.  Same-address atomics serialise at
-// the memory side (~10 ns each): never one per pair (that WAS the whole narrowphase launch once), and
-// not even one per 256 pairs -- a grid-stride loop over at most kStatsBlocks blocks, one atomic pair each.
-constexpr uint32_t kStatsBlocks = 128;
-
-__global__ void k_manifold_stats(const ContactManifold *__restrict__ m, uint32_t n_pairs, unsigned long long *__restrict__ stats)
-{
-    uint32_t points = 0, touching = 0;
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += gridDim.x * blockDim.x) {
-        const uint32_t n = m[p].n_points;
-        points += n;
-        touching += n ? 1u : 0u;
-    }
-    for (uint32_t off = 32; off; off >>= 1) {
-        points += __shfl_xor(points, off, 64);
-        touching += __shfl_xor(touching, off, 64);
-    }
-    __shared__ uint32_t part[2][4];
-    if ((threadIdx.x & 63u) == 0) {
-        part[0][threadIdx.x >> 6] = touching;
-        part[1][threadIdx.x >> 6] = points;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&stats[0], (unsigned long long)(part[0][0] + part[0][1] + part[0][2] + part[0][3]));
-        atomicAdd(&stats[1], (unsigned long long)(part[1][0] + part[1][1] + part[1][2] + part[1][3]));
-    }
-}
-
 } // namespace
-
-hipError_t launch_manifold_stats(const ContactManifold *m, uint32_t n_pairs, unsigned long long *stats, hipStream_t stream)
-{
-    if (n_pairs && stats) {
-        const uint32_t nb = (n_pairs + 255) / 256;
-        hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, m, n_pairs, stats);
-    }
-    return hipGetLastError();
-}
 
 namespace {
 // Lanes per pair and vertex capacity by the largest shape: boxes and tetrahedra (<= 8 vertices and faces) run four
@@ -598,8 +560,7 @@ hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, con
 }
 
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, unsigned long long *stats, SatScratch *list,
-                               hipStream_t stream)
+                               uint32_t n_pairs, ContactManifold *out, SatScratch *list, hipStream_t stream)
 {
     if (n_pairs == 0)
         return hipSuccess;
@@ -614,10 +575,6 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
             hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         }
     });
-    if (stats) {
-        const uint32_t nb = (n_pairs + 255) / 256;
-        hipLaunchKernelGGL(k_manifold_stats, dim3(nb < kStatsBlocks ? nb : kStatsBlocks), dim3(256), 0, stream, out, n_pairs, stats);
-    }
     return hipGetLastError();
 }
 

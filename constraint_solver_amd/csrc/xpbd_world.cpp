@@ -297,7 +297,6 @@ int narrowphase_contacts(xpbd_world *w, const xpbd::BodyArrays &b, const xpbd::C
             return rc;
         XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds,
                                                 w->gjk_scratch, true, w->sat_two_pass ? &w->sat_scratch : nullptr, w->stream));
-        XPBD_HIP_TRY(xpbd::launch_manifold_stats(c.manifolds, w->n_pairs, c.stats, w->stream));
     } else {
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
                                                     w->stream));
