@@ -13,6 +13,14 @@ struct Joint {
     double distance;
 };
 
+// The uniform grid of one broadphase (device, written by k_grid).
+struct GridInfo {
+    double edge;        // cell edge = 2 * largest bounding radius
+    int32_t origin[3];  // dense mode: cell of the box's minimum corner, minus the margin cell
+    uint32_t dims[3];   //             cells per axis including the margins
+    uint32_t dense;     // 1: bucket key = linear cell index (no two cells share a bucket); 0: hashed cell
+};
+
 // Device buffers of the contact pipeline (owned by the world, sized by the host).
 struct ContactBuffers {
     // broadphase, per body
@@ -20,7 +28,8 @@ struct ContactBuffers {
     double *radius;         // [stride]    r_shape + min(|v| dt, r_shape) + pad
     int32_t *cell;          // [3][stride] grid cell of the centre
     uint32_t *key;          // [stride]    hash bucket of that cell
-    unsigned long long *max_radius_bits; // [1]
+    GridInfo *grid;         // [1]
+    double *grid_partials;  // [workgroups of k_bounds][7] largest radius, min xyz, max xyz of the centres
     // hash table, table_size = power of two
     uint32_t *bucket_start; // [table_size + 1] counts -> exclusive scan
     uint32_t *bucket_cursor;// [table_size]

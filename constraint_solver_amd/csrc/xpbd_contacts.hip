@@ -121,52 +121,131 @@ __global__ void k_scan_add(uint32_t *__restrict__ data, uint32_t n, const uint32
 // ---------------------------------------------------------------------------------------------------
 // Bounding sphere of every body: centre = frame * centroid, radius = r_shape + min(|v| dt, r_shape) + pad.
 // The clamp keeps one runaway body from inflating the grid cell of everybody (cell edge = 2 * max radius).
-__global__ void k_bounds(BodyArrays b, PolytopeTables t, const double *__restrict__ shape_radius, double dt, double pad,
-                         ContactBuffers c)
+// Every workgroup also leaves the largest radius and the bounding box of its centres in c.grid_partials (7 doubles
+// per workgroup: no atomics); k_grid reduces them.
+__global__ void __launch_bounds__(kBlock) k_bounds(BodyArrays b, PolytopeTables t, const double *__restrict__ shape_radius, double dt,
+                                                   double pad, ContactBuffers c)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    double r = 0.0;
+    double v[7] = {0.0, DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX}; // rmax, min xyz, max xyz
     if (i < b.n) {
         const uint32_t sid = b.shape_id[i];
         const double *cc = t.centroids + 3 * (size_t)sid;
         const Vec3 centre = body_frame(b, i) * Vec3{cc[0], cc[1], cc[2]};
         const Vec3 vel = load3(b.dyn, D_VEL, b.stride, i);
         const double rs = shape_radius[sid], travel = length(vel) * dt;
-        r = rs + (travel < rs ? travel : rs) + pad;
+        const double r = rs + (travel < rs ? travel : rs) + pad;
         store3(c.centers, 0, b.stride, i, centre);
         c.radius[i] = r;
+        v[0] = (r > 0.0 && r <= DBL_MAX) ? r : 0.0;
+        const double xyz[3] = {centre.x, centre.y, centre.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { // a NaN coordinate opens the box completely: the grid then falls back to hashing
+            v[1 + a] = xyz[a] == xyz[a] ? xyz[a] : -DBL_MAX;
+            v[4 + a] = xyz[a] == xyz[a] ? xyz[a] : DBL_MAX;
+        }
     }
-    // positive finite doubles order like their bit patterns; one atomic per wave (same-address atomics serialize)
-    unsigned long long bits = (r > 0.0 && r <= DBL_MAX) ? (unsigned long long)__double_as_longlong(r) : 0ull;
-    for (uint32_t off = 32; off; off >>= 1) {
-        const unsigned long long other = __shfl_xor(bits, off, 64);
-        bits = other > bits ? other : bits;
+    __shared__ double part[kBlock / 64][7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        double x = v[q];
+        for (uint32_t off = 32; off; off >>= 1) {
+            const double o = __shfl_xor(x, off, 64);
+            x = (q >= 1 && q <= 3) ? (o < x ? o : x) : (o > x ? o : x);
+        }
+        if ((threadIdx.x & 63u) == 0)
+            part[threadIdx.x >> 6][q] = x;
     }
-    if ((threadIdx.x & 63u) == 0 && bits)
-        atomicMax(c.max_radius_bits, bits);
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const uint32_t q = threadIdx.x;
+        double x = part[0][q];
+        for (uint32_t w = 1; w < kBlock / 64; ++w) {
+            const double o = part[w][q];
+            x = (q >= 1 && q <= 3) ? (o < x ? o : x) : (o > x ? o : x);
+        }
+        c.grid_partials[(size_t)blockIdx.x * 7 + q] = x;
+    }
 }
 
-// Grid cell (edge = 2 * largest radius, so overlapping spheres sit in adjacent cells) and bucket count.
+__device__ __forceinline__ double clamp_cell(double q)
+{
+    if (!(q >= -1.0e9)) // NaN or far negative
+        q = -1.0e9;
+    return q > 1.0e9 ? 1.0e9 : q;
+}
+
+// One workgroup: reduces the partials of k_bounds to the grid of this broadphase.  Cell edge = 2 * largest radius, so
+// overlapping spheres sit in adjacent cells.  When the box of all centres (plus one cell of margin on every side)
+// has no more cells than the table has buckets, the bucket key is the LINEAR cell index (`dense`): neighbouring
+// cells are neighbouring buckets, the 27 lookups of a body become 9 runs of 3 consecutive entries and bodies next to
+// each other share them.  Otherwise the key is a hash of the cell and buckets may hold several cells.
+__global__ void __launch_bounds__(kBlock) k_grid(ContactBuffers c, uint32_t n_partials)
+{
+    __shared__ double part[kBlock / 64][7];
+    double v[7] = {0.0, DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (uint32_t k = threadIdx.x; k < n_partials; k += kBlock)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const double o = c.grid_partials[(size_t)k * 7 + q];
+            v[q] = (q >= 1 && q <= 3) ? (o < v[q] ? o : v[q]) : (o > v[q] ? o : v[q]);
+        }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        double x = v[q];
+        for (uint32_t off = 32; off; off >>= 1) {
+            const double o = __shfl_xor(x, off, 64);
+            x = (q >= 1 && q <= 3) ? (o < x ? o : x) : (o > x ? o : x);
+        }
+        if ((threadIdx.x & 63u) == 0)
+            part[threadIdx.x >> 6][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    for (int q = 0; q < 7; ++q)
+        for (uint32_t w = 1; w < kBlock / 64; ++w) {
+            const double o = part[w][q];
+            part[0][q] = (q >= 1 && q <= 3) ? (o < part[0][q] ? o : part[0][q]) : (o > part[0][q] ? o : part[0][q]);
+        }
+    GridInfo g;
+    g.edge = 2.0 * part[0][0];
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = g.edge > 0.0 ? clamp_cell(floor(part[0][1 + a] / g.edge)) : 0.0;
+        const double hi = g.edge > 0.0 ? clamp_cell(floor(part[0][4 + a] / g.edge)) : 0.0;
+        const double dim = hi >= lo ? hi - lo + 3.0 : 3.0; // one cell of margin on either side
+        g.origin[a] = (int32_t)lo - 1;
+        g.dims[a] = dim <= 2147483647.0 ? (uint32_t)dim : 0x7FFFFFFFu;
+        cells *= dim;
+    }
+    g.dense = (g.edge > 0.0 && cells <= (double)c.table_size) ? 1u : 0u;
+    *c.grid = g;
+}
+
+__device__ __forceinline__ uint32_t cell_key(const GridInfo &g, uint32_t table_size, int32_t x, int32_t y, int32_t z)
+{
+    if (g.dense)
+        return (uint32_t)(x - g.origin[0]) + g.dims[0] * ((uint32_t)(y - g.origin[1]) + g.dims[1] * (uint32_t)(z - g.origin[2]));
+    return cell_hash(x, y, z) & (table_size - 1);
+}
+
+// Grid cell of every body and the population count of its bucket.
 __global__ void k_cells(BodyArrays b, ContactBuffers c)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n)
         return;
-    const double edge = 2.0 * __longlong_as_double((long long)*c.max_radius_bits);
+    const GridInfo g = *c.grid;
     const Vec3 centre = load3(c.centers, 0, b.stride, i);
     int32_t cell[3];
     const double coord[3] = {centre.x, centre.y, centre.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        double q = edge > 0.0 ? floor(coord[a] / edge) : 0.0;
-        if (!(q >= -1.0e9))   // NaN or far negative
-            q = -1.0e9;
-        if (q > 1.0e9)
-            q = 1.0e9;
-        cell[a] = (int32_t)q;
+        cell[a] = (int32_t)(g.edge > 0.0 ? clamp_cell(floor(coord[a] / g.edge)) : 0.0);
         c.cell[(size_t)a * b.stride + i] = cell[a];
     }
-    const uint32_t key = cell_hash(cell[0], cell[1], cell[2]) & (c.table_size - 1);
+    const uint32_t key = cell_key(g, c.table_size, cell[0], cell[1], cell[2]);
     c.key[i] = key;
     atomicAdd(&c.bucket_start[key], 1u);
 }
@@ -238,9 +317,10 @@ __device__ __forceinline__ void for_each_neighbour(const BodyArrays &b, const Co
     int32_t cx = 0, cy = 0, cz = 0;
     if (live) {
         cx = c.cell[i], cy = c.cell[st + i], cz = c.cell[2 * st + i];
+        const GridInfo grid = *c.grid;
         for (uint32_t k = cl; k < 27; k += kCellLanes) {
             const int32_t nx = cx + (int32_t)(k % 3) - 1, ny = cy + (int32_t)((k / 3) % 3) - 1, nz = cz + (int32_t)(k / 9) - 1;
-            const uint32_t key = cell_hash(nx, ny, nz) & (c.table_size - 1);
+            const uint32_t key = cell_key(grid, c.table_size, nx, ny, nz);
             const uint32_t lo = c.bucket_start[key];
             r.start[g][k] = lo;
             r.len[g][k] = c.bucket_start[key + 1] - lo;
@@ -731,14 +811,13 @@ hipError_t launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *scratch, 
 hipError_t launch_bounds_and_cells(const BodyArrays &b, const PolytopeTables &t, const double *shape_radius,
                                    double dt, double pad, const ContactBuffers &c, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(c.max_radius_bits, 0, sizeof(unsigned long long), stream);
-    if (e == hipSuccess)
-        e = hipMemsetAsync(c.bucket_start, 0, (size_t)(c.table_size + 1) * 4, stream);
+    hipError_t e = hipMemsetAsync(c.bucket_start, 0, (size_t)(c.table_size + 1) * 4, stream);
     if (e == hipSuccess)
         e = hipMemsetAsync(c.bucket_cursor, 0, (size_t)c.table_size * 4, stream);
     if (e != hipSuccess || b.n == 0)
         return e;
     hipLaunchKernelGGL(k_bounds, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, t, shape_radius, dt, pad, c);
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(kBlock), 0, stream, c, blocks_for(b.n));
     hipLaunchKernelGGL(k_cells, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, c);
     return hipGetLastError();
 }

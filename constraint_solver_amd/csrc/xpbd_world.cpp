@@ -120,6 +120,7 @@ struct xpbd_world {
         cb_past_pos, cb_manifolds, cb_stats, cb_scan, cb_slot_sphere, cb_slot_cell;
     // second set of per-substep frames for the fused "end of substep k + start of substep k + 1" kernel (step_contacts)
     DeviceBuffer cb_frame_p1_b, cb_frame_past_b, cb_past_pos_b;
+    DeviceBuffer cb_grid_partials;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
@@ -146,7 +147,8 @@ struct xpbd_world {
         c.radius = cb_radius.as<double>();
         c.cell = cb_cell.as<int32_t>();
         c.key = cb_key.as<uint32_t>();
-        c.max_radius_bits = cb_maxr.as<unsigned long long>();
+        c.grid = cb_maxr.as<xpbd::GridInfo>();
+        c.grid_partials = cb_grid_partials.as<double>();
         c.bucket_start = cb_bucket_start.as<uint32_t>();
         c.bucket_cursor = cb_bucket_cursor.as<uint32_t>();
         c.items = cb_items.as<uint32_t>();
@@ -222,7 +224,8 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_radius.reserve((size_t)st * 8));
     XPBD_HIP_TRY(w->cb_cell.reserve((size_t)3 * st * 4));
     XPBD_HIP_TRY(w->cb_key.reserve((size_t)st * 4));
-    XPBD_HIP_TRY(w->cb_maxr.reserve(8));
+    XPBD_HIP_TRY(w->cb_maxr.reserve(sizeof(xpbd::GridInfo)));
+    XPBD_HIP_TRY(w->cb_grid_partials.reserve(((size_t)st / 256 + 1) * 7 * 8));
     XPBD_HIP_TRY(w->cb_bucket_start.reserve((size_t)(w->table_size + 1) * 4));
     XPBD_HIP_TRY(w->cb_bucket_cursor.reserve((size_t)w->table_size * 4));
     XPBD_HIP_TRY(w->cb_items.reserve((size_t)st * 4));
@@ -443,7 +446,8 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
-                            &w->sat_counters, &w->sat_survivors, &w->cb_frame_p1_b, &w->cb_frame_past_b, &w->cb_past_pos_b})
+                            &w->sat_counters, &w->sat_survivors, &w->cb_frame_p1_b, &w->cb_frame_past_b, &w->cb_past_pos_b,
+                            &w->cb_grid_partials})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);

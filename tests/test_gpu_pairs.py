@@ -122,10 +122,15 @@ def pile(kind, n, seed, width, height):
 
 
 @pytest.mark.parametrize("kind,n,spread", [(capi.SCENE_BOXES, 3000, 12.0), (capi.SCENE_MIXED, 2000, 6.0),
-                                           (capi.SCENE_BOXES, 70, 1.0), (capi.SCENE_MIXED, 300, 0.5)])
+                                           (capi.SCENE_BOXES, 70, 1.0), (capi.SCENE_MIXED, 300, 0.5),
+                                           (capi.SCENE_MIXED, 1500, -6.0)])
 def test_broadphase_matches_brute_force(kind, n, spread):
-    """(the 300-body clump gives every body 299 neighbours: the one-lane path for lists beyond the LDS stage)"""
-    bodies, sid = cluster(kind, n, 5, spread)
+    """(the 300-body clump gives every body 299 neighbours: the one-lane path for lists beyond the LDS stage; a
+    negative spread adds three bodies millions of metres away, which makes the box of all centres too large for a
+    dense grid: the hashed-cell path)"""
+    bodies, sid = cluster(kind, n, 5, abs(spread))
+    if spread < 0:
+        bodies[[3, 700, 1499], 31:34] = [[4.0e6, 0.0, 0.0], [4.0e6, 0.4, 0.1], [-2.5e6, 7.0e5, 1.0e6]]
     bodies[::7, 22:25] *= 30.0                                     # some fast bodies: radius grows with |v| dt
     with capi.World() as w:
         w.set_polytopes(capi.scene_polytopes(kind))
