@@ -363,10 +363,11 @@ __global__ void __launch_bounds__(kBlock) k_neighbour_count(BodyArrays b, Contac
 {
     __shared__ CellRanges ranges;
     const uint32_t g = threadIdx.x / kCellLanes, cl = threadIdx.x % kCellLanes;
-    // bodies in INDEX order: callers number bodies coherently in space more often than not, and bodies of one cell
-    // share their 27 lookups; bucket order under a scattering hash is a random order (tried: 178 -> 335 us on `stacks`)
-    const uint32_t i = blockIdx.x * kBodiesPerBlock + g;
-    const bool live = i < b.n;
+    // bodies in BUCKET order when the grid is dense (= cell order: the groups of a workgroup then search the same few
+    // cells), in index order under the scattering hash (bucket order is a random order there: 178 -> 335 us on `stacks`)
+    const uint32_t slot = blockIdx.x * kBodiesPerBlock + g;
+    const bool live = slot < b.n;
+    const uint32_t i = (live && c.grid->dense) ? c.items[slot] : slot;
     uint32_t all = 0, upper = 0;
     for_each_neighbour(b, c, ranges, i, live, g, cl, [&](uint32_t j) {
         ++all;
@@ -391,8 +392,9 @@ __global__ void __launch_bounds__(kBlock) k_neighbour_fill(BodyArrays b, Contact
     __shared__ uint32_t stage[kBodiesPerBlock][kNbrStage];
     __shared__ uint32_t cursor[kBodiesPerBlock];
     const uint32_t g = threadIdx.x / kCellLanes, cl = threadIdx.x % kCellLanes;
-    const uint32_t i = blockIdx.x * kBodiesPerBlock + g;
-    const bool live = i < b.n;
+    const uint32_t slot = blockIdx.x * kBodiesPerBlock + g;
+    const bool live = slot < b.n;
+    const uint32_t i = (live && c.grid->dense) ? c.items[slot] : slot;
     uint32_t lo = 0, total = 0;
     if (live) {
         lo = c.nbr_off[i];
