@@ -33,7 +33,7 @@ struct PolytopeTables {
     const double *edge_dirs;     // [total_dirs][3] shape-local direction v[e.1] - v[e.0] of the first edge with it
     const uint32_t *edge_dir_id; // [total_edges] shape-local index of every edge's direction
     uint32_t n_shapes;
-    uint32_t max_verts, max_faces; // of the largest shape: the narrowphase launchers pick their sub-wave width by them
+    uint32_t max_verts, max_faces, max_face_verts; // over all shapes: the narrowphase launchers pick their sub-wave width by them
 };
 
 constexpr uint32_t kMaxManifoldPoints = 8;

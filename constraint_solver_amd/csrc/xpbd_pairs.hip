@@ -32,22 +32,42 @@ constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS; // 32
 #ifndef XPBD_SAT_MIN_WAVES_PER_SIMD
 #define XPBD_SAT_MIN_WAVES_PER_SIMD 4 // <= 128 VGPRs
 #endif
+#ifndef XPBD_SAT_BOX_LANES
+#define XPBD_SAT_BOX_LANES 8 // shapes of <= 8 vertices and faces with <= 4 vertices per face: clipped polygons have <= 8 vertices
+#endif
 #ifndef XPBD_SAT_MID_LANES
 #define XPBD_SAT_MID_LANES 32 // A/B on 65 536 mixed polyhedra: 16 lanes 5.19e8, 32 lanes 5.59e8 body-substeps/s
 #endif
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kWidePairCount = 32768; // 8 pairs per wave x 4 096 wave slots (1 024 SIMDs x 4)
 
-// Working set of one pair.  V = vertex capacity per body (the launcher picks the group width from the largest shape:
-// 16 lanes <=> at most 8 vertices, 32 <=> 16, 64 <=> kMaxV); PAD staggers the records of the pairs of a wave over
-// the LDS banks -- all groups read "vertex k of my pair" in the same instruction, and records that are a multiple of
-// 64 dwords apart would put those reads on the same banks (measured: SQ_LDS_BANK_CONFLICT = 86 % of the LDS cycles).
-template <uint32_t V, uint32_t PAD>
+// Working set of one pair.  V = vertex capacity per body, P = polygon capacity of the clipper (the launcher picks the
+// group width and both from the largest shape).  The tail pads the record so that its stride
+// staggers the records of the PW pairs of a wave over the LDS banks -- all groups read "vertex k of my pair" in the
+// same instruction, and records a multiple of 64 dwords apart would put those reads on the same banks (measured:
+// SQ_LDS_BANK_CONFLICT = 86 % of the LDS cycles).
+template <uint32_t V, uint32_t P, uint32_t PW>
 struct PairLds {
+    static constexpr uint32_t kBaseDwords = 2 * (2 * 2 * V * 3 + 2 * P * 3 + kMaxFaceVerts * 3);
+    // record stride = an ODD multiple of 64 / PW dwords (mod 64): the PW records then start on PW different bank
+    // groups; of the candidates take the one that needs the least padding
+    static constexpr uint32_t pad_dwords()
+    {
+        if (PW == 1)
+            return 0;
+        uint32_t best = 64;
+        for (uint32_t odd = 1; odd < 2 * PW; odd += 2) {
+            const uint32_t pad = (odd * (64 / PW) + 64 - kBaseDwords % 64) % 64;
+            best = pad < best ? pad : best;
+        }
+        return best;
+    }
+    static constexpr uint32_t kPadDwords = pad_dwords();
     double world[2][V][3]; // world-space vertices of A (0) and B (1)
     double local[2][V][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space
-    double poly[2][16][3]; // clipping ping-pong
+    double poly[2][P][3];  // clipping ping-pong
     double ref[kMaxFaceVerts][3]; // the reference face's vertices, staged once for the clipping loop
-    uint32_t pad[16 + (PAD ? PAD : 1)]; // 16: `ref` is 48 dwords, this keeps the unpadded record a multiple of 64
+    uint32_t pad[kPadDwords ? kPadDwords : 2];
 };
 
 __device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
@@ -136,7 +156,9 @@ template <uint32_t L, class Lds, class M>
 __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane)
 {
-    constexpr uint32_t H = L / 2; // lanes per body in the two-sided stages
+    constexpr uint32_t H = L / 2;             // lanes per body in the two-sided stages
+    constexpr uint32_t P = L < 16 ? L : 16;   // polygon capacity of the clipper: one vertex per lane, at most 16 (the
+                                              // launcher uses L = 8 only where no polygon can exceed 8 vertices)
     // ---- group-uniform inputs ---------------------------------------------------------------------
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
@@ -364,18 +386,18 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
         const uint32_t emit = (in0 ? 1u : 0u) + (crossing ? 1u : 0u);
         uint32_t inc = emit;
 #pragma unroll
-        for (uint32_t d = 1; d < 16; d <<= 1) {
+        for (uint32_t d = 1; d < P; d <<= 1) {
             const uint32_t up = __shfl_up(inc, d, L);
             if (lane >= d)
                 inc += up;
         }
-        const uint32_t total = __shfl(inc, 15, L);
+        const uint32_t total = __shfl(inc, P - 1, L);
         uint32_t slot = inc - emit;
-        if (in0 && slot < 16)
+        if (in0 && slot < P)
             st3(s.poly[cur ^ 1u], slot++, p0);
-        if (crossing && slot < 16)
+        if (crossing && slot < P)
             st3(s.poly[cur ^ 1u], slot, p0 + (p1 - p0) * (d0 / (d0 - d1)));
-        np = total < 16 ? total : 16;
+        np = total < P ? total : P;
         cur ^= 1u;
         __syncthreads();
     }
@@ -390,12 +412,12 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     }
     uint32_t inc = keep ? 1u : 0u;
 #pragma unroll
-    for (uint32_t d = 1; d < 16; d <<= 1) {
+    for (uint32_t d = 1; d < P; d <<= 1) {
         const uint32_t up = __shfl_up(inc, d, L);
         if (lane >= d)
             inc += up;
     }
-    const uint32_t kept = __shfl(inc, 15, L);
+    const uint32_t kept = __shfl(inc, P - 1, L);
     const uint32_t n_out = kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
     if (keep && inc - 1 < kMaxManifoldPoints) {
         const uint32_t at = inc - 1;
@@ -428,10 +450,10 @@ __device__ __forceinline__ bool tight_spheres_overlap(const BodyArrays &b, const
 
 template <uint32_t L, uint32_t V>
 struct SatLds {
-    static constexpr uint32_t PW = 64 / L; // pairs per wave
+    static constexpr uint32_t PW = 64 / L;            // pairs per wave
+    static constexpr uint32_t P = L < 16 ? L : 16;    // one polygon vertex per lane, at most 16
     static_assert(V == 8 || V == 16 || V == kMaxV, "vertex capacity per body");
-    // record size in dwords is a multiple of 64 for every V above: pad by 64 / PW dwords (two dwords keep 8-byte alignment)
-    using Record = PairLds<V, PW == 1 ? 0u : 64u / PW>;
+    using Record = PairLds<V, P, PW>;
     static_assert(sizeof(Record) % 8 == 0, "pair records must stay 8-byte aligned");
 };
 
@@ -521,12 +543,17 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
 
 namespace {
 // Lanes per pair and vertex capacity by the largest shape: boxes and tetrahedra (<= 8 vertices and faces) run four
-// pairs per wave with 8-vertex records; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with 16-vertex
-// records; anything larger gets a whole wave.
+// pairs per wave with 8-vertex records -- eight when no face has more than 4 vertices (a clipped polygon then has at
+// most 8, one per lane) and the launch is large; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
+// 16-vertex records; anything larger gets a whole wave.
 template <class Launch>
-void for_shape_class(const PolytopeTables &t, Launch launch)
+void for_shape_class(const PolytopeTables &t, uint32_t n_pairs, Launch launch)
 {
-    if (t.max_verts <= 8 && t.max_faces <= 8)
+    // 8 lanes per pair halve the instructions per pair of the clipping half of the SAT (208 -> 148 us on 245 760 box
+    // pairs) but lengthen the chain of a wave: only when there are enough pairs to fill the GPU with 8-pair waves
+    if (t.max_verts <= 8 && t.max_faces <= 8 && t.max_face_verts <= 4 && n_pairs >= kWidePairCount)
+        launch(std::integral_constant<uint32_t, XPBD_SAT_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
+    else if (t.max_verts <= 8 && t.max_faces <= 8)
         launch(std::integral_constant<uint32_t, 16>{}, std::integral_constant<uint32_t, 8>{});
     else if (t.max_verts <= 16)
         launch(std::integral_constant<uint32_t, XPBD_SAT_MID_LANES>{}, std::integral_constant<uint32_t, 16>{});
@@ -539,7 +566,7 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
                             uint32_t n_pairs, Manifold *out, hipStream_t stream)
 {
     if (n_pairs)
-        for_shape_class(t, [&](auto lanes, auto verts) {
+        for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_pairs<L, V, false, Manifold>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
                                frames, pairs, n_pairs, out);
@@ -564,7 +591,7 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
 {
     if (n_pairs == 0)
         return hipSuccess;
-    for_shape_class(t, [&](auto lanes, auto verts) {
+    for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
         constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
         const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
         if (list) { // pre-test pass, then the SAT over the survivors

@@ -103,13 +103,13 @@ struct xpbd_world {
     DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
     DeviceBuffer shape_radii, edge_dirs, edge_dir_id;
     bool has_topology = false;
-    uint32_t max_verts = 0, max_faces = 0;
+    uint32_t max_verts = 0, max_faces = 0, max_face_verts = 0;
     xpbd::PolytopeTables tables() const
     {
         return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
                                     shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
                                     face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(),
-                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, max_verts, max_faces};
+                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, max_verts, max_faces, max_face_verts};
     }
 
     // extension: contact pipeline (XPBD_MODE_CONTACTS)
@@ -591,13 +591,18 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
     XPBD_HIP_TRY(upload(w->edge_dirs, dirs.data(), dirs.size() * 8));
     XPBD_HIP_TRY(upload(w->edge_dir_id, dir_id.data(), dir_id.size() * 4));
     w->has_topology = true;
-    uint32_t max_verts = 0, max_faces = 0;
+    uint32_t max_verts = 0, max_faces = 0, max_face_verts = 0;
     for (uint32_t k = 0; k < n_shapes; ++k) {
         max_verts = shapes[k].n_vertices > max_verts ? shapes[k].n_vertices : max_verts;
         max_faces = shapes[k].n_faces > max_faces ? shapes[k].n_faces : max_faces;
+        for (uint32_t f = 0; f < shapes[k].n_faces; ++f) {
+            const uint32_t nfv = shapes[k].face_offsets[f + 1] - shapes[k].face_offsets[f];
+            max_face_verts = nfv > max_face_verts ? nfv : max_face_verts;
+        }
     }
     w->max_verts = max_verts;
     w->max_faces = max_faces;
+    w->max_face_verts = max_face_verts;
     return XPBD_OK;
 }
 

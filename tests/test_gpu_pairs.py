@@ -64,6 +64,32 @@ def test_narrowphase_matches_oracle(kind, n, spread):
     assert 0.05 * len(want) < touching < 0.95 * len(want)           # and so did separated pairs
 
 
+def test_large_box_launches_use_eight_lanes_per_pair_and_still_match_the_oracle():
+    """From 32 768 pairs on, box-like shapes run eight pairs per wave (8 lanes each; vertex, face and edge-axis loops take
+    two trips, one clipped-polygon vertex per lane).  The diagnostic entry point on 36 000 random box pairs, and the
+    whole pipeline on 2 304 sixteen-high columns (34 560 pairs per substep), against the oracle."""
+    n = 400
+    bodies, sid = cluster(capi.SCENE_BOXES, n, 17, 2.4)
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, n, (36500, 2)).astype(np.uint32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    assert len(pairs) >= 32768 + 3000
+    with capi.World() as w:
+        w.set_polytopes(capi.scene_polytopes(capi.SCENE_BOXES))
+        w.upload(bodies, sid)
+        got = w.narrowphase(pairs)
+    feats = assert_same(got, oracle_manifolds(bodies, sid, pairs))
+    assert feats == {0, 1, 2}
+
+    n = 2304 * 16
+    bodies, sid = capi.scene_generate(capi.SCENE_BOX_STACKS, 3, n)
+    bodies[:, 33] = (np.arange(n) % 16) * 0.9995                   # every vertical pair touches from the first substep
+    got, gm, gs, want, wm, ws = run_contacts(bodies, sid, capi.SCENE_BOXES, 4, 2)
+    assert ws[0][0] == 2304 * 15 and ws[0][1] == 4 * 2304 * 15
+    assert gs == ws and np.array_equal(gm, wm)
+    assert bits_equal(got, want)
+
+
 def test_stacked_boxes_give_four_point_manifolds():
     n = 64
     bodies, sid = capi.scene_generate(capi.SCENE_BOXES, 1, n)
