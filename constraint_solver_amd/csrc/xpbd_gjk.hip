@@ -6,7 +6,7 @@
 // support(frame_a, d) - support(frame_b, -d) -- here with one polytope per frame.
 //
 // Two kernels, because most broadphase pairs are separated and never need a polytope:
-//  * k_gjk_pairs<L>: the boolean GJK, L = 16 or 32 lanes per pair (4 or 2 pairs per wave).  Both vertex
+//  * k_gjk_pairs<L>: the boolean GJK, L = 8 or 32 lanes per pair (8 or 2 pairs per wave).  Both vertex
 //    sets live in LDS (world space).  A support query: the first half of the group strides over A's
 //    vertices, the second half over B's, a __shfl_xor (key, index) reduction per half picks the last
 //    maximum.  The simplex (<= 4 points with their witnesses) stays in registers, identical on every
@@ -20,6 +20,7 @@
 // the order of the hit list.
 #include <cfloat>
 #include <climits>
+#include <type_traits>
 
 #include "xpbd_device.hpp"
 #include "xpbd_gjk.h"
@@ -27,6 +28,9 @@
 namespace xpbd {
 namespace {
 
+#ifndef XPBD_GJK_SMALL_LANES
+#define XPBD_GJK_SMALL_LANES 8 // A/B on 262 144 mixed polyhedra: 16 lanes 1.06e9, 8 lanes 1.12e9 body-substeps/s
+#endif
 constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
@@ -555,7 +559,6 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + n_pairs);
     uint32_t *count = scratch.counters + (scratch.calls & 1u), *next = scratch.counters + ((scratch.calls + 1u) & 1u);
     ++scratch.calls;
-    const dim3 grid16((n_pairs + 3) / 4), grid32((n_pairs + 1) / 2);
     const uint32_t *survivors = nullptr;
     uint32_t *survivor_count = nullptr, *next_survivor_count = nullptr;
     if (sphere_pretest && list && manifolds) { // two-pass form: the pre-test pass answers the rejected pairs
@@ -564,18 +567,22 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         survivors = list->survivors;
         sphere_pretest = false; // the survivors have passed it
     }
-    if (t.max_verts <= 16 && sphere_pretest) // 16 lanes per pair, four pairs per wave
-        hipLaunchKernelGGL((k_gjk_pairs<16, true>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                           next_survivor_count, out, manifolds, count, hits, seeds);
+    auto launch = [&](auto lanes, auto pretest) {
+        constexpr uint32_t L = decltype(lanes)::value;
+        hipLaunchKernelGGL((k_gjk_pairs<L, decltype(pretest)::value>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
+                           frames, pairs, n_pairs, survivors, survivor_count, next_survivor_count, out, manifolds, count, hits, seeds);
+    };
+    using std::integral_constant;
+    // lanes per pair: XPBD_GJK_SMALL_LANES for shapes of at most 16 vertices (the simplex logic is replicated on every
+    // lane of a group, so narrow groups amortise it over more pairs), 32 above
+    if (t.max_verts <= 16 && sphere_pretest)
+        launch(integral_constant<uint32_t, XPBD_GJK_SMALL_LANES>{}, std::true_type{});
     else if (t.max_verts <= 16)
-        hipLaunchKernelGGL((k_gjk_pairs<16, false>), grid16, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                           next_survivor_count, out, manifolds, count, hits, seeds);
+        launch(integral_constant<uint32_t, XPBD_GJK_SMALL_LANES>{}, std::false_type{});
     else if (sphere_pretest)
-        hipLaunchKernelGGL((k_gjk_pairs<32, true>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                           next_survivor_count, out, manifolds, count, hits, seeds);
+        launch(integral_constant<uint32_t, 32>{}, std::true_type{});
     else
-        hipLaunchKernelGGL((k_gjk_pairs<32, false>), grid32, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                           next_survivor_count, out, manifolds, count, hits, seeds);
+        launch(integral_constant<uint32_t, 32>{}, std::false_type{});
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
     hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, next, hits,
                        seeds);
