@@ -10,6 +10,7 @@
 // and every order they leave open is removed by a sort.  Results do not depend on launch order,
 // on the hash-table size or on how the world is sharded.
 #include <cfloat>
+#include <type_traits>
 
 #include "xpbd_contacts.h"
 #include "xpbd_step.hpp"
@@ -18,6 +19,12 @@ namespace xpbd {
 namespace {
 
 constexpr uint32_t kBlock = 256;
+// Worlds up to this many bodies run the pair solve with one lane per manifold POINT (eight lanes per body): below it
+// the GPU is not full and a substep costs the dependent chain of one wave, which this shortens.
+#ifndef XPBD_SMALL_WORLD
+#define XPBD_SMALL_WORLD 16384
+#endif
+constexpr uint32_t kSmallWorld = XPBD_SMALL_WORLD;
 #ifndef XPBD_PAIR_SOLVE_MIN_WAVES
 #define XPBD_PAIR_SOLVE_MIN_WAVES 2
 #endif
@@ -591,9 +598,16 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
 // Jacobi pair solve + joints + derive of body i: its state at the end of the substep.
 // (touching, points: += the manifolds with contact points among this body's pairs (i, j > i) and their points -- every
 // pair is counted by its smaller body, which gives the pipeline's statistics without a pass of their own)
+//
+// G = lanes per body.  G = 1: the lane walks the points of a manifold one after the other.  G = 8 (small worlds, where
+// a wave's dependent chain is the whole cost): lane `sub` evaluates point `sub` of the manifold, and the terms are then
+// added on every lane in point order -- the same values in the same order, so the same bits.
+template <uint32_t G>
 __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i, double h,
-                                                              const PairBody &self, uint32_t &touching, uint32_t &points)
+                                                              const PairBody &self, uint32_t sub, uint32_t &touching,
+                                                              uint32_t &points)
 {
+    static_assert(G == 1 || G == kMaxManifoldPoints, "one lane per body or one lane per manifold point");
     const uint32_t st = b.stride;
     const double compliance = 1e-6 / (h * h);
 
@@ -618,7 +632,8 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
         const bool self_is_a = i < j;
         const bool ref_is_a = m->feature != 1u;
         const bool self_is_inc = self_is_a != ref_is_a;
-        for (uint32_t pt = 0; pt < n_points; ++pt) {
+        // one contact point: what it adds to dpos and drot
+        auto point_term = [&](uint32_t pt, Vec3 &term_pos, Quat &term_rot) {
             const Vec3 p_inc{m->point[pt][0][0], m->point[pt][0][1], m->point[pt][0][2]};
             const Vec3 p_ref{m->point[pt][1][0], m->point[pt][1][1], m->point[pt][1][2]};
             const Vec3 p_self = self_is_inc ? p_inc : p_ref, p_other = self_is_inc ? p_ref : p_inc;
@@ -636,11 +651,31 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
             const double lambda = (dist - 0.0) / (w + compliance);
 
             const Vec3 impulse = self_is_inc ? lambda * dir : (-lambda) * dir;
-            dpos = dpos + impulse * self.inv_mass;
+            term_pos = impulse * self.inv_mass;
             const Vec3 arm = p_self - (self.pos + self.com);
             const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
-            drot = drot + (0.5 * spin) * self.rot;
-            ++count;
+            term_rot = (0.5 * spin) * self.rot;
+        };
+        if (G == 1) {
+            for (uint32_t pt = 0; pt < n_points; ++pt) {
+                Vec3 term_pos;
+                Quat term_rot;
+                point_term(pt, term_pos, term_rot);
+                dpos = dpos + term_pos;
+                drot = drot + term_rot;
+                ++count;
+            }
+        } else {
+            Vec3 term_pos{0.0, 0.0, 0.0};
+            Quat term_rot{0.0, 0.0, 0.0, 0.0};
+            if (sub < n_points)
+                point_term(sub, term_pos, term_rot);
+            for (uint32_t pt = 0; pt < n_points; ++pt) { // every lane of the group adds the terms in point order
+                dpos = dpos + Vec3{__shfl(term_pos.x, pt, G), __shfl(term_pos.y, pt, G), __shfl(term_pos.z, pt, G)};
+                drot = drot + Quat{__shfl(term_rot.s, pt, G), __shfl(term_rot.x, pt, G), __shfl(term_rot.y, pt, G),
+                                   __shfl(term_rot.z, pt, G)};
+                ++count;
+            }
         }
     }
 
@@ -710,16 +745,19 @@ __device__ __forceinline__ void block_add_stats(uint32_t touching, uint32_t poin
     }
 }
 
+template <uint32_t G>
 __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
                                                                                         ContactBuffers c)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, i = gid / G, sub = gid % G;
     uint32_t touching = 0, points = 0;
     if (i < b.n) {
         const PairBody self = load_pair_body(b, c, i);
-        store_dynamic(dyn_out, b.stride, i, pair_solve_derive_body(b, c, i, h, self, touching, points));
+        const BodyDynamic d = pair_solve_derive_body<G>(b, c, i, h, self, sub, touching, points);
+        if (sub == 0)
+            store_dynamic(dyn_out, b.stride, i, d);
     }
-    block_add_stats(touching, points, c.stats);
+    block_add_stats(sub == 0 ? touching : 0u, sub == 0 ? points : 0u, c.stats);
 }
 
 // The end of substep k and the beginning of substep k + 1 of one body in one kernel: pair solve + derive, then
@@ -728,7 +766,9 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
 // buffer and the frames of substep k + 1 to the other frame set (`next`).  Saves the store + reload of the dynamic
 // state, half of the static loads and one launch per substep; same arithmetic, same bits.  Only for step calls
 // that run all their substeps on one device: a halo exchange sits exactly at this seam.
-template <bool TRACE>
+// (G lanes per body as in pair_solve_derive_body; with G = 8 the integrate + ground part runs redundantly on the eight
+// lanes and lane 0 stores.)
+template <bool TRACE, uint32_t G>
 __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_integrate_ground(
     BodyArrays b, ShapeTable shapes, double *__restrict__ dyn_out, double h, ContactBuffers c, double *__restrict__ next_frame_p1,
     double *__restrict__ next_frame_past, double *__restrict__ next_past_pos, uint32_t *__restrict__ last_mask,
@@ -742,14 +782,14 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         lds_off[k] = shapes.offsets[k];
     __syncthreads();
 
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, i = gid / G, sub = gid % G;
     uint32_t touching = 0, points = 0;
     if (i < b.n) {
         const uint32_t st = b.stride;
         BodyDynamic d;
         {
             const PairBody self = load_pair_body(b, c, i);
-            d = pair_solve_derive_body(b, c, i, h, self, touching, points);
+            d = pair_solve_derive_body<G>(b, c, i, h, self, sub, touching, points);
         }
         const Vec3 derived_vel = d.vel, derived_ang = d.ang; // what memory holds between substeps (k_integrate_ground keeps
                                                               // its integrated velocities in registers only)
@@ -758,18 +798,22 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         const uint32_t v0 = lds_off[sid];
         const double compliance = 1e-6 / (h * h);
         const SubstepFrames f = integrate_body(d, s, h);
-        store_frame(next_frame_past, st, i, f.past);
-        store_frame(next_frame_p1, st, i, f.cur);
-        store3(next_past_pos, 0, st, i, f.past_pos);
+        if (sub == 0) {
+            store_frame(next_frame_past, st, i, f.past);
+            store_frame(next_frame_p1, st, i, f.cur);
+            store3(next_past_pos, 0, st, i, f.past_pos);
+        }
         const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
         d.vel = derived_vel;
         d.ang = derived_ang;
-        store_dynamic(dyn_out, st, i, d);
-        last_mask[i] = mask;
-        if (TRACE)
-            trace_masks[(size_t)trace_row * st + i] = mask;
+        if (sub == 0) {
+            store_dynamic(dyn_out, st, i, d);
+            last_mask[i] = mask;
+            if (TRACE)
+                trace_masks[(size_t)trace_row * st + i] = mask;
+        }
     }
-    block_add_stats(touching, points, c.stats);
+    block_add_stats(sub == 0 ? touching : 0u, sub == 0 ? points : 0u, c.stats);
 }
 
 // Halo exchange: one lane per (body, field); the buffer side is contiguous, the SoA side is a gather.
@@ -880,8 +924,13 @@ hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
                                     hipStream_t stream)
 {
-    if (b.n)
-        hipLaunchKernelGGL(k_pair_solve_derive, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
+    if (b.n == 0)
+        return hipSuccess;
+    if (b.n <= kSmallWorld)
+        hipLaunchKernelGGL(k_pair_solve_derive<kMaxManifoldPoints>, dim3(blocks_for(b.n * kMaxManifoldPoints)), dim3(kBlock), 0, stream, b,
+                           dyn_out, h, c);
+    else
+        hipLaunchKernelGGL(k_pair_solve_derive<1>, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
     return hipGetLastError();
 }
 
@@ -893,12 +942,22 @@ hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTa
     if (b.n == 0)
         return hipSuccess;
     const size_t lds_bytes = (size_t)s.total_verts * 3 * sizeof(double) + (size_t)(s.n_shapes + 1) * sizeof(uint32_t);
-    if (trace_masks)
-        hipLaunchKernelGGL(k_pair_solve_integrate_ground<true>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, dyn_out, h, c,
-                           next_frame_p1, next_frame_past, next_past_pos, last_mask, trace_masks, trace_row);
+    auto launch = [&](auto trace, auto lanes) {
+        constexpr uint32_t G = decltype(lanes)::value;
+        hipLaunchKernelGGL((k_pair_solve_integrate_ground<decltype(trace)::value, G>), dim3(blocks_for(b.n * G)), dim3(kBlock), lds_bytes,
+                           stream, b, s, dyn_out, h, c, next_frame_p1, next_frame_past, next_past_pos, last_mask, trace_masks, trace_row);
+    };
+    using Wide = std::integral_constant<uint32_t, kMaxManifoldPoints>;
+    using One = std::integral_constant<uint32_t, 1>;
+    const bool small = b.n <= kSmallWorld;
+    if (trace_masks && small)
+        launch(std::true_type{}, Wide{});
+    else if (trace_masks)
+        launch(std::true_type{}, One{});
+    else if (small)
+        launch(std::false_type{}, Wide{});
     else
-        hipLaunchKernelGGL(k_pair_solve_integrate_ground<false>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, dyn_out, h, c,
-                           next_frame_p1, next_frame_past, next_past_pos, last_mask, trace_masks, trace_row);
+        launch(std::false_type{}, One{});
     return hipGetLastError();
 }
 
