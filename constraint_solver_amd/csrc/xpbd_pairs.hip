@@ -35,6 +35,9 @@ constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS; // 32
 #ifndef XPBD_SAT_BOX_LANES
 #define XPBD_SAT_BOX_LANES 8 // shapes of <= 8 vertices and faces with <= 4 vertices per face: clipped polygons have <= 8 vertices
 #endif
+#ifndef XPBD_SAT_SMALL_LANES
+#define XPBD_SAT_SMALL_LANES 16 // shapes of <= 8 vertices and faces otherwise
+#endif
 #ifndef XPBD_SAT_MID_LANES
 #define XPBD_SAT_MID_LANES 32 // A/B on 65 536 mixed polyhedra: 16 lanes 5.19e8, 32 lanes 5.59e8 body-substeps/s
 #endif
@@ -554,7 +557,7 @@ void for_shape_class(const PolytopeTables &t, uint32_t n_pairs, Launch launch)
     if (t.max_verts <= 8 && t.max_faces <= 8 && t.max_face_verts <= 4 && n_pairs >= kWidePairCount)
         launch(std::integral_constant<uint32_t, XPBD_SAT_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
     else if (t.max_verts <= 8 && t.max_faces <= 8)
-        launch(std::integral_constant<uint32_t, 16>{}, std::integral_constant<uint32_t, 8>{});
+        launch(std::integral_constant<uint32_t, XPBD_SAT_SMALL_LANES>{}, std::integral_constant<uint32_t, 8>{});
     else if (t.max_verts <= 16)
         launch(std::integral_constant<uint32_t, XPBD_SAT_MID_LANES>{}, std::integral_constant<uint32_t, 16>{});
     else
