@@ -169,19 +169,6 @@ __device__ __forceinline__ void store_face(GjkLds &s, uint32_t slot, const Face 
     s.fd[slot] = f.dist;
 }
 
-__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t lane, uint32_t *total)
-{
-    uint32_t inc = v;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, 64);
-        if (lane >= d)
-            inc += up;
-    }
-    *total = __shfl(inc, 63, 64);
-    return inc - v;
-}
-
 // First face with the smallest plane distance (all lanes return the same index).
 __device__ __forceinline__ uint32_t closest_face(const GjkLds &s, uint32_t nf, uint32_t lane, double *dist_out)
 {
@@ -444,11 +431,29 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
             }
         }
         // canonical slots: surviving faces keep their order; horizon edges ordered by (face, edge)
+        // (exclusive prefix sums over the lanes of 0/1 flags and of 3-bit edge masks: a ballot per bit and a popcount
+        // of the lanes below, instead of a six-step shuffle scan each)
+        const unsigned long long below = (1ull << lane) - 1ull;
+        auto flag_scan = [&](bool flag, uint32_t *total) {
+            const unsigned long long m = __ballot(flag);
+            *total = (uint32_t)__popcll(m);
+            return (uint32_t)__popcll(m & below);
+        };
+        auto edge_scan = [&](uint32_t bits, uint32_t *total) {
+            uint32_t before = 0;
+            *total = 0;
+            for (uint32_t e = 0; e < 3; ++e) {
+                const unsigned long long m = __ballot((bits >> e) & 1u);
+                before += (uint32_t)__popcll(m & below);
+                *total += (uint32_t)__popcll(m);
+            }
+            return before;
+        };
         uint32_t keep_a, keep_b, ne_a, ne_b;
-        const uint32_t kpos0 = wave_exclusive_scan((f0 < nf && !vis0) ? 1u : 0u, lane, &keep_a);
-        const uint32_t kpos1 = keep_a + wave_exclusive_scan((f1 < nf && !vis1) ? 1u : 0u, lane, &keep_b);
-        const uint32_t epos0 = wave_exclusive_scan(__popc(hz[0]), lane, &ne_a);
-        const uint32_t epos1 = ne_a + wave_exclusive_scan(__popc(hz[1]), lane, &ne_b);
+        const uint32_t kpos0 = flag_scan(f0 < nf && !vis0, &keep_a);
+        const uint32_t kpos1 = keep_a + flag_scan(f1 < nf && !vis1, &keep_b);
+        const uint32_t epos0 = edge_scan(hz[0], &ne_a);
+        const uint32_t epos1 = ne_a + edge_scan(hz[1], &ne_b);
         const uint32_t keep = keep_a + keep_b, ne = ne_a + ne_b;
         if (ne == 0 || keep + ne > kMaxEpaFaces)
             break; // numerical dead end or out of room: report the best face found so far
