@@ -135,6 +135,14 @@ __device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint3
     }
 }
 
+// The bits of a wave-wide ballot that belong to the calling lane's group of L lanes, moved down to bit 0.
+template <uint32_t L>
+__device__ __forceinline__ uint64_t group_bits(unsigned long long wave_mask)
+{
+    const uint32_t first = (threadIdx.x & 63u) / L * L; // the block is one wave
+    return L == 64 ? wave_mask : (wave_mask >> first) & ((1ull << (L & 63u)) - 1ull);
+}
+
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
 // The SAT of ONE pair by a group of L lanes (`lane` = lane inside the group, `s` = the group's LDS record).
@@ -386,16 +394,12 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
             in0 = d0 <= 0.0;
             crossing = in0 != (d1 <= 0.0);
         }
-        const uint32_t emit = (in0 ? 1u : 0u) + (crossing ? 1u : 0u);
-        uint32_t inc = emit;
-#pragma unroll
-        for (uint32_t d = 1; d < P; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, L);
-            if (lane >= d)
-                inc += up;
-        }
-        const uint32_t total = __shfl(inc, P - 1, L);
-        uint32_t slot = inc - emit;
+        // slots of the 0 / 1 / 2 points a lane emits = points emitted by the lanes below it: two ballots and popcounts
+        // over the group's bits of the wave mask (a shuffle scan would be log2(P) round trips)
+        const uint64_t in_bits = group_bits<L>(__ballot(in0)), cross_bits = group_bits<L>(__ballot(crossing));
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint32_t total = (uint32_t)(__popcll(in_bits) + __popcll(cross_bits));
+        uint32_t slot = (uint32_t)(__popcll(in_bits & below) + __popcll(cross_bits & below));
         if (in0 && slot < P)
             st3(s.poly[cur ^ 1u], slot++, p0);
         if (crossing && slot < P)
@@ -413,17 +417,11 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
         depth = distance(ref_plane, pt);
         keep = !(depth >= 0.0);
     }
-    uint32_t inc = keep ? 1u : 0u;
-#pragma unroll
-    for (uint32_t d = 1; d < P; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, L);
-        if (lane >= d)
-            inc += up;
-    }
-    const uint32_t kept = __shfl(inc, P - 1, L);
+    const uint64_t keep_bits = group_bits<L>(__ballot(keep));
+    const uint32_t kept = (uint32_t)__popcll(keep_bits);
     const uint32_t n_out = kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
-    if (keep && inc - 1 < kMaxManifoldPoints) {
-        const uint32_t at = inc - 1;
+    const uint32_t at = (uint32_t)__popcll(keep_bits & ((1ull << lane) - 1ull));
+    if (keep && at < kMaxManifoldPoints) {
         const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
         set_point(*m, at, pt, on_ref);
     }
