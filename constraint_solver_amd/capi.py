@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
     "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
     "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
-    "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_set_joints",
+    "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_import_dynamic_rows", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
     "xpbd_world_set_sat_schedule",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
@@ -135,6 +135,7 @@ def hip_lib():
         L.xpbd_world_contacts_substep.argtypes = [C.c_void_p, C.c_double]
         L.xpbd_world_export_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.xpbd_world_import_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_import_dynamic_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.xpbd_world_set_sat_schedule.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_world_history_push.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.xpbd_world_history_restore.argtypes = [C.c_void_p, C.c_uint32]
@@ -318,6 +319,11 @@ class World:
 
     def import_dynamic(self, dev_indices_ptr, n, dev_buf_ptr):
         _check(hip_lib().xpbd_world_import_dynamic(self._h, C.c_void_p(dev_indices_ptr), n, C.c_void_p(dev_buf_ptr)))
+
+    def import_dynamic_rows(self, dev_indices_ptr, dev_rows_ptr, n, dev_buf_ptr):
+        """Body indices[k] takes row rows[k] of the buffer (device pointers; rows are uint32)."""
+        _check(hip_lib().xpbd_world_import_dynamic_rows(self._h, C.c_void_p(dev_indices_ptr), C.c_void_p(dev_rows_ptr), n,
+                                                        C.c_void_p(dev_buf_ptr)))
 
     def set_sat_schedule(self, schedule):
         """SAT_SCHEDULE_AUTO / _ONE_PASS / _TWO_PASS (same results, different cost)."""

@@ -92,7 +92,8 @@ hipError_t launch_body_frames_aos(const BodyArrays &b, double *frames, hipStream
 
 // Halo exchange: gather / scatter the 13 dynamic fields of the listed bodies, body-major buffer.
 hipError_t launch_export_dynamic(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *buf, hipStream_t stream);
-hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *buf, hipStream_t stream);
+hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, const uint32_t *rows, uint32_t n, const double *buf,
+                                 hipStream_t stream); // rows: NULL = row k of buf for entry k
 
 // Exclusive scan of data[0..n) in place; data[n] receives the total.  scratch: >= n/1024 + 2 uint32.
 hipError_t launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *scratch, hipStream_t stream);

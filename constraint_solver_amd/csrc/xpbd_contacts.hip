@@ -826,13 +826,16 @@ __global__ void k_export_dynamic(BodyArrays b, const uint32_t *__restrict__ indi
     buf[t] = b.dyn[(size_t)f * b.stride + indices[k]];
 }
 
-__global__ void k_import_dynamic(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n, const double *__restrict__ buf)
+// (rows: optional; entry k of the list then comes from row rows[k] of buf instead of row k -- the gathered halo
+// buffer of an all-gather can be imported as it is)
+__global__ void k_import_dynamic(BodyArrays b, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ rows, uint32_t n,
+                                 const double *__restrict__ buf)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * kDynFields)
         return;
     const uint32_t k = t / kDynFields, f = t - k * kDynFields;
-    b.dyn[(size_t)f * b.stride + indices[k]] = buf[t];
+    b.dyn[(size_t)f * b.stride + indices[k]] = buf[(size_t)(rows ? rows[k] : k) * kDynFields + f];
 }
 
 uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
@@ -975,10 +978,11 @@ hipError_t launch_export_dynamic(const BodyArrays &b, const uint32_t *indices, u
     return hipGetLastError();
 }
 
-hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *buf, hipStream_t stream)
+hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, const uint32_t *rows, uint32_t n, const double *buf,
+                                 hipStream_t stream)
 {
     if (n)
-        hipLaunchKernelGGL(k_import_dynamic, dim3(blocks_for(n * kDynFields)), dim3(kBlock), 0, stream, b, indices, n, buf);
+        hipLaunchKernelGGL(k_import_dynamic, dim3(blocks_for(n * kDynFields)), dim3(kBlock), 0, stream, b, indices, rows, n, buf);
     return hipGetLastError();
 }
 

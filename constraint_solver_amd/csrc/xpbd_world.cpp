@@ -972,7 +972,18 @@ int xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32
         return fail(XPBD_E_INVALID, "xpbd_world_import_dynamic: NULL argument");
     if (int rc = bind_device(w))
         return rc;
-    XPBD_HIP_TRY(xpbd::launch_import_dynamic(w->arrays(), dev_indices, n, dev_buf, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_import_dynamic(w->arrays(), dev_indices, nullptr, n, dev_buf, w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_import_dynamic_rows(xpbd_world *w, const uint32_t *dev_indices, const uint32_t *dev_rows, uint32_t n,
+                                   const double *dev_buf)
+{
+    if (!w || (n && (!dev_indices || !dev_rows || !dev_buf)))
+        return fail(XPBD_E_INVALID, "xpbd_world_import_dynamic_rows: NULL argument");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_import_dynamic(w->arrays(), dev_indices, dev_rows, n, dev_buf, w->stream));
     return XPBD_OK;
 }
 

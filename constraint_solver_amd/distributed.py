@@ -142,10 +142,9 @@ class GpuBackend:
     def export(self, idx, out):
         self.world.export_dynamic(idx.data_ptr(), idx.numel(), out.data_ptr())
 
-    def import_(self, idx, buf):
-        buf = buf.contiguous()
-        self.world.import_dynamic(idx.data_ptr(), idx.numel(), buf.data_ptr())
-        self._keep = buf                           # alive until the stream has consumed it
+    def import_rows(self, idx, rows, buf):
+        """Local slots idx[k] take row rows[k] of buf (the gathered halo buffer, imported as it is)."""
+        self.world.import_dynamic_rows(idx.data_ptr(), rows.data_ptr(), idx.numel(), buf.data_ptr())
 
     def empty(self, rows):
         return self.torch.empty((rows, DYN_FIELDS), dtype=self.torch.float64, device=self.device)
@@ -199,7 +198,7 @@ class ShardedContactWorld:
         b.upload(bodies_global[ids], self.shape_id_global[ids], local_joints)
         self.boundary_idx = b.index_tensor(boundary_slots)
         self.ghost_idx = b.index_tensor(ghost_slots)
-        self.ghost_rows = b.torch.as_tensor(rows, device=self.boundary_idx.device)
+        self.ghost_rows = b.index_tensor(rows)
         self.send = b.empty(self.plan.capacity)
         self.recv = b.empty(self.plan.capacity * self.world_size)
         self.n_boundary = len(boundary_slots)
@@ -223,7 +222,7 @@ class ShardedContactWorld:
         else:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         if len(self.ghost_rows):
-            b.import_(self.ghost_idx, self.recv[self.ghost_rows])
+            b.import_rows(self.ghost_idx, self.ghost_rows, self.recv)
 
     def step(self, dt, substeps):
         """xpbd_world_step(dt, substeps) of the whole sharded world (lock step over ranks)."""

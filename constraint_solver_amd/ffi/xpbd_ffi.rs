@@ -148,6 +148,7 @@ extern "C" {
     pub fn xpbd_world_contacts_substep(w: *mut XpbdWorld, h: f64) -> c_int;
     pub fn xpbd_world_export_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *mut f64) -> c_int;
     pub fn xpbd_world_import_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *const f64) -> c_int;
+    pub fn xpbd_world_import_dynamic_rows(w: *mut XpbdWorld, dev_indices: *const u32, dev_rows: *const u32, n: u32, dev_buf: *const f64) -> c_int;
     // state history: replaces `states: Vec<(World, DebugLines)>` of src/app.rs:48 (see HistoryWorld below)
     pub fn xpbd_world_history_push(w: *mut XpbdWorld, index_out: *mut u32) -> c_int;
     pub fn xpbd_world_history_restore(w: *mut XpbdWorld, index: u32) -> c_int;

@@ -265,6 +265,10 @@ int  xpbd_world_contacts_substep(xpbd_world *w, double h);
  * collective enqueued on the same stream (or ordered after it) sees the data. */
 int  xpbd_world_export_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_buf);
 int  xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_buf);
+/* As import_dynamic, but body dev_indices[k] takes row dev_rows[k] of dev_buf: the output of an all-gather (every
+ * rank's boundary bodies back to back) is imported as it is, without a gather pass of the host framework. */
+int  xpbd_world_import_dynamic_rows(xpbd_world *w, const uint32_t *dev_indices, const uint32_t *dev_rows, uint32_t n,
+                                    const double *dev_buf);
 
 /* State history: the device-side counterpart of the reference app's `states: Vec<(World,
  * DebugLines)>` with its `current_state` cursor (src/app.rs:48, 206-212), which lets the user

@@ -57,9 +57,9 @@ class OracleBackend:
     def export(self, idx, out):
         out.copy_(self.torch.from_numpy(self.bodies[idx.numpy()][:, DYN_AOS_COLUMNS]))
 
-    def import_(self, idx, buf):
-        rows = idx.numpy()
-        self.bodies[rows[:, None], DYN_AOS_COLUMNS[None, :]] = buf.numpy()
+    def import_rows(self, idx, rows, buf):
+        slots = idx.numpy()
+        self.bodies[slots[:, None], DYN_AOS_COLUMNS[None, :]] = buf.numpy()[rows.numpy()]
 
     def empty(self, rows):
         return self.torch.empty((rows, DYN_FIELDS), dtype=self.torch.float64)
