@@ -34,6 +34,7 @@ struct ContactBuffers {
     uint32_t *bucket_start; // [table_size + 1] counts -> exclusive scan
     uint32_t *bucket_cursor;// [table_size]
     uint32_t *items;        // [n] body ids grouped by bucket, ascending inside a bucket
+    uint32_t *items_unsorted; // [n] the same in scatter (arrival) order
     uint32_t table_size;
     double *slot_sphere;    // [4][stride] centre xyz and radius of items[s], i.e. in bucket order
     int32_t *slot_cell;     // [3][stride] cell of items[s]

@@ -120,7 +120,7 @@ struct xpbd_world {
         cb_past_pos, cb_manifolds, cb_stats, cb_scan, cb_slot_sphere, cb_slot_cell;
     // second set of per-substep frames for the fused "end of substep k + start of substep k + 1" kernel (step_contacts)
     DeviceBuffer cb_frame_p1_b, cb_frame_past_b, cb_past_pos_b;
-    DeviceBuffer cb_grid_partials;
+    DeviceBuffer cb_grid_partials, cb_items_unsorted;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
@@ -152,6 +152,7 @@ struct xpbd_world {
         c.bucket_start = cb_bucket_start.as<uint32_t>();
         c.bucket_cursor = cb_bucket_cursor.as<uint32_t>();
         c.items = cb_items.as<uint32_t>();
+        c.items_unsorted = cb_items_unsorted.as<uint32_t>();
         c.table_size = table_size;
         c.slot_sphere = cb_slot_sphere.as<double>();
         c.slot_cell = cb_slot_cell.as<int32_t>();
@@ -229,6 +230,7 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_bucket_start.reserve((size_t)(w->table_size + 1) * 4));
     XPBD_HIP_TRY(w->cb_bucket_cursor.reserve((size_t)w->table_size * 4));
     XPBD_HIP_TRY(w->cb_items.reserve((size_t)st * 4));
+    XPBD_HIP_TRY(w->cb_items_unsorted.reserve((size_t)st * 4));
     XPBD_HIP_TRY(w->cb_slot_sphere.reserve((size_t)4 * st * 8));
     XPBD_HIP_TRY(w->cb_slot_cell.reserve((size_t)3 * st * 4));
     XPBD_HIP_TRY(w->cb_nbr_off.reserve((size_t)(st + 1) * 4));
@@ -447,7 +449,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
                             &w->sat_counters, &w->sat_survivors, &w->cb_frame_p1_b, &w->cb_frame_past_b, &w->cb_past_pos_b,
-                            &w->cb_grid_partials})
+                            &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
