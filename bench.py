@@ -281,13 +281,24 @@ def main():
         result["config"]["ground_contacts_per_body_after_run"] = len(world.contacts()) / max(count, 1)
         if mode == capi.MODE_CONTACTS:
             pairs, touching, points = world.contact_stats()
-            result["config"]["extension"] = ("body-body contacts: NOT in the reference (parity unpinned); roofline "
-                                             "fields price only the per-body state traffic")
+            all_substeps = max((args.steps + args.warmup) * args.substeps, 1)
+            touching_per_substep, points_per_substep = touching / all_substeps, points / all_substeps
+            result["config"]["extension"] = "body-body contacts: NOT in the reference (parity unpinned)"
             result["config"]["joints"] = args.joints
             result["config"]["narrowphase"] = args.narrowphase
             result["config"]["neighbour_pairs"] = pairs
-            result["config"]["touching_pairs_per_substep"] = touching / max((args.steps + args.warmup) * args.substeps, 1)
-            result["config"]["manifold_points_per_substep"] = points / max((args.steps + args.warmup) * args.substeps, 1)
+            result["config"]["touching_pairs_per_substep"] = touching_per_substep
+            result["config"]["manifold_points_per_substep"] = points_per_substep
+            # Algorithmic bytes of ONE SUBSTEP of the pipeline (narrowphase + the fused per-body kernel), DESIGN.md 8:
+            # per body 716 B (state 13 + 25 doubles, frames in 14 + out 17 doubles, state out 13, shape id), per listed
+            # pair 120 B (two frames, the pair), per touching pair its 24-byte header written once and read by both
+            # bodies, per contact point 48 B written once and read twice.
+            substep_bytes = count * 716 + pairs * 120 + touching_per_substep * 72 + points_per_substep * 144
+            result["roofline"].update({
+                "achieved": substep_bytes / launch_s / 1e9, "frac": substep_bytes / launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "one substep: narrowphase + k_pair_solve_integrate_ground", "bytes_per_launch": substep_bytes,
+                "note": "whole-substep figure (the SAT is f64-VALU / latency bound, the per-body kernel bandwidth bound; "
+                        "per-kernel times in profiles/r01_o_contacts_*_kernel_stats.csv)"})
         if world_size == 1 and mode == capi.MODE_FUSED and not args.no_extras:
             # The same kernel scheduled one launch per substep (state round-trips HBM every substep):
             # the HBM-roofline-comparable form, measured in the same run on the same resident state.
