@@ -72,6 +72,8 @@ def test_null_arguments_are_errors_not_crashes():
     assert L.xpbd_world_set_shapes(None, None, None, 0) == capi.E_INVALID
     assert L.xpbd_step_one(None, None, 0, 1 / 60, 1) == capi.E_INVALID
     assert L.xpbd_world_body_count(None) == 0
+    assert L.xpbd_world_import_dynamic_rows(None, None, None, 0, None) == capi.E_INVALID
+    assert L.xpbd_world_set_sat_schedule(None, 0) == capi.E_INVALID
     assert L.xpbd_world_history_push(None, None) == capi.E_INVALID
     assert L.xpbd_world_history_restore(None, 0) == capi.E_INVALID
     assert L.xpbd_world_history_truncate(None, 0) == capi.E_INVALID
