@@ -51,6 +51,7 @@ constexpr uint32_t kWidePairCount = 32768; // 8 pairs per wave x 4 096 wave slot
 // SQ_LDS_BANK_CONFLICT = 86 % of the LDS cycles).
 template <uint32_t V, uint32_t P, uint32_t PW>
 struct PairLds {
+    static constexpr uint32_t kVerts = V;
     static constexpr uint32_t kBaseDwords = 2 * (2 * 2 * V * 3 + 2 * P * 3 + kMaxFaceVerts * 3);
     // record stride = an ODD multiple of 64 / PW dwords (mod 64): the PW records then start on PW different bank
     // groups; of the candidates take the one that needs the least padding
@@ -230,9 +231,28 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     uint32_t eq = kNone;
     const double *cca = t.centroids + 3 * (size_t)sa, *ccb = t.centroids + 3 * (size_t)sb;
     const Vec3 a_to_b = fb * Vec3{ccb[0], ccb[1], ccb[2]} - fa * Vec3{cca[0], cca[1], cca[2]};
+    // The world-space edge directions of both bodies, once per pair: every axis below is the cross product of one of
+    // A's with one of B's, and rotating them inside the axis loop cost two quaternion rotations and six global loads
+    // per axis.  They take the place of `local` (the face queries above were its last readers) when they fit.
+    const bool dirs_staged = da.n_dirs <= Lds::kVerts && db.n_dirs <= Lds::kVerts;
+    __syncthreads();
+    if (dirs_staged) {
+        for (uint32_t d = lane; d < da.n_dirs + db.n_dirs; d += L) {
+            const bool of_b = d >= da.n_dirs;
+            const uint32_t kd = of_b ? d - da.n_dirs : d;
+            const double *dd = t.edge_dirs + 3 * (size_t)((of_b ? db.dir0 : da.dir0) + kd);
+            st3(s.local[of_b ? 1 : 0], kd, (of_b ? fb : fa).rotation * Vec3{dd[0], dd[1], dd[2]});
+        }
+        __syncthreads();
+    }
     auto edge_axis = [&](uint32_t i, uint32_t j, Vec3 &axis) -> bool {
-        const double *da_ = t.edge_dirs + 3 * (size_t)(da.dir0 + i), *db_ = t.edge_dirs + 3 * (size_t)(db.dir0 + j);
-        Vec3 n = normalized(cross(fa.rotation * Vec3{da_[0], da_[1], da_[2]}, fb.rotation * Vec3{db_[0], db_[1], db_[2]}));
+        Vec3 n;
+        if (dirs_staged) {
+            n = normalized(cross(ld3(s.local[0], i), ld3(s.local[1], j)));
+        } else {
+            const double *da_ = t.edge_dirs + 3 * (size_t)(da.dir0 + i), *db_ = t.edge_dirs + 3 * (size_t)(db.dir0 + j);
+            n = normalized(cross(fa.rotation * Vec3{da_[0], da_[1], da_[2]}, fb.rotation * Vec3{db_[0], db_[1], db_[2]}));
+        }
         if (!finite3(n))
             return false;
         if (dot(n, a_to_b) < 0.0)
