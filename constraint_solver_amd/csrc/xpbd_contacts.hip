@@ -613,11 +613,24 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
     Vec3 dpos{0.0, 0.0, 0.0};
     Quat drot{0.0, 0.0, 0.0, 0.0};
     uint32_t count = 0;
-    for (uint32_t k = c.nbr_off[i]; k < c.nbr_off[i + 1]; ++k) {
-        const ContactManifold *m = c.manifolds + c.nbr_pair[k];
-        const uint32_t n_points = m->n_points;
+    // The neighbours in batches of four: their pair indices, then their point counts, are fetched side by side, so a
+    // body pays two dependent round trips per batch instead of two per neighbour (most neighbours of a loose scene
+    // do not touch, and the whole cost of looking at them is that latency).  Processing order stays ascending.
+    const uint32_t k_end = c.nbr_off[i + 1];
+    for (uint32_t k0 = c.nbr_off[i]; k0 < k_end; k0 += 4) {
+      uint32_t pair_of[4], points_of[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+          pair_of[u] = k0 + u < k_end ? c.nbr_pair[k0 + u] : 0u;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+          points_of[u] = k0 + u < k_end ? c.manifolds[pair_of[u]].n_points : 0u;
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t n_points = u == 0 ? points_of[0] : (u == 1 ? points_of[1] : (u == 2 ? points_of[2] : points_of[3]));
         if (n_points == 0)
             continue;
+        const uint32_t k = k0 + u;
+        const ContactManifold *m = c.manifolds + (u == 0 ? pair_of[0] : (u == 1 ? pair_of[1] : (u == 2 ? pair_of[2] : pair_of[3])));
         const uint32_t j = c.nbr[k];
         if (j > i) {
             ++touching;
@@ -676,6 +689,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
                 ++count;
             }
         }
+      }
     }
 
     // joints of this body, ascending joint index (same accumulator: the "mixed-constraint" pass)
