@@ -47,6 +47,9 @@ struct ShapeTable {
 // read 13 dyn + 25 stat doubles + 4 B shape id, write 13 dyn doubles.
 constexpr uint32_t kBytesPerBodySubstep = (13 + 25) * 8 + 4 + 13 * 8; // 412
 
+// Largest workgroup launch_step accepts (k_step's __launch_bounds__).
+constexpr uint32_t kMaxStepBlock = 256;
+
 // Runs `substeps` substeps of solver::step (src/solver.rs:6-16) for every body,
 // in one launch.  h = dt / substep_count (src/solver.rs:4) is computed by the caller.
 // last_mask[i]      <- contact mask of the final substep (always written).

@@ -24,7 +24,6 @@ namespace {
 // k_step: `substeps` substeps for every body in one launch.
 // LDS: the shape vertex tables (<= a few hundred bytes), staged once per block.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kMaxStepBlock = 256;
 #ifndef XPBD_STEP_MIN_WAVES_PER_SIMD
 #define XPBD_STEP_MIN_WAVES_PER_SIMD 1
 #endif

@@ -91,6 +91,7 @@ struct xpbd_world {
     // bodies
     uint32_t n = 0;
     uint32_t stride = 0;
+    uint32_t max_shape_id = 0; // largest shape id among the uploaded bodies (xpbd_world_set_shapes re-validates against it)
     DeviceBuffer dyn, stat, shape_id, aos_staging, last_mask, trace, block_counts, contacts;
     uint32_t trace_rows = 0; // substeps recorded by the last step()
     bool stepped = false;
@@ -399,9 +400,10 @@ int xpbd_world_create(xpbd_world **out, const xpbd_config *cfg)
         return fail(XPBD_E_INVALID, "xpbd_world_create: unknown mode %u", c.mode);
     if (c.flags & ~XPBD_FLAG_TRACE_CONTACTS)
         return fail(XPBD_E_INVALID, "xpbd_world_create: unknown flags 0x%x", c.flags);
-    if (c.block_size != 0 && (c.block_size % 64 != 0 || c.block_size > 1024))
-        return fail(XPBD_E_INVALID, "xpbd_world_create: block_size %u must be a multiple of 64, <= 1024",
-                    c.block_size);
+    // k_step is compiled with __launch_bounds__(xpbd::kMaxStepBlock): a larger workgroup is a launch failure
+    if (c.block_size != 0 && (c.block_size % 64 != 0 || c.block_size > xpbd::kMaxStepBlock))
+        return fail(XPBD_E_INVALID, "xpbd_world_create: block_size %u must be a multiple of 64, <= %u",
+                    c.block_size, xpbd::kMaxStepBlock);
     if (c.reserved[0] || c.reserved[1] || c.reserved[2])
         return fail(XPBD_E_INVALID, "xpbd_world_create: reserved fields must be 0");
 
@@ -474,6 +476,10 @@ int xpbd_world_set_shapes(xpbd_world *w, const double *verts_xyz, const uint32_t
     // The tables are staged into LDS by every block; keep them far below the 160 KiB/CU.
     if ((size_t)total * 24 + (size_t)(n_shapes + 1) * 4 > 48 * 1024)
         return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: shape tables exceed 48 KiB");
+    // the resident bodies keep their shape ids: the kernels index the staged table with them unchecked
+    if (w->n && n_shapes <= w->max_shape_id)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_shapes: %u shapes, but the uploaded bodies use shape id %u (upload bodies "
+                                    "again after shrinking the table)", n_shapes, w->max_shape_id);
     if (int rc = bind_device(w))
         return rc;
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
@@ -643,11 +649,14 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
         return fail(XPBD_E_INVALID, "xpbd_world_upload_bodies: NULL argument");
     if (w->n_shapes == 0)
         return fail(XPBD_E_INVALID, "xpbd_world_upload_bodies: call xpbd_world_set_shapes first");
+    uint32_t max_shape_id = 0;
     if (shape_id)
-        for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t i = 0; i < n; ++i) {
             if (shape_id[i] >= w->n_shapes)
                 return fail(XPBD_E_INVALID, "xpbd_world_upload_bodies: shape_id[%u] = %u >= n_shapes %u", i,
                             shape_id[i], w->n_shapes);
+            max_shape_id = shape_id[i] > max_shape_id ? shape_id[i] : max_shape_id;
+        }
     if (int rc = bind_device(w))
         return rc;
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
@@ -664,6 +673,7 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     XPBD_HIP_TRY(w->aos_staging.reserve((size_t)(n ? n : 1) * sizeof(xpbd_rigid)));
     w->n = n;
     w->stride = stride;
+    w->max_shape_id = max_shape_id;
     w->stepped = false;
     w->trace_rows = 0;
     if (n == 0)
@@ -899,6 +909,8 @@ int xpbd_world_set_joints(xpbd_world *w, const xpbd_joint *joints, uint32_t n_jo
     static_assert(sizeof(xpbd_joint) == sizeof(xpbd::Joint), "xpbd_joint must mirror xpbd::Joint");
     if (!w || (n_joints && !joints))
         return fail(XPBD_E_INVALID, "xpbd_world_set_joints: NULL argument");
+    if (n_joints && w->mode != XPBD_MODE_CONTACTS) // only the contact pipeline projects joints: do not accept and ignore them
+        return fail(XPBD_E_INVALID, "xpbd_world_set_joints: joints need XPBD_MODE_CONTACTS (world is in mode %u)", w->mode);
     std::vector<uint32_t> off((size_t)w->n + 2, 0), list((size_t)2 * n_joints);
     for (uint32_t k = 0; k < n_joints; ++k) {
         const xpbd_joint &j = joints[k];
@@ -1085,9 +1097,13 @@ int xpbd_world_history_push(xpbd_world *w, uint32_t *index_out)
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? XPBD_E_OOM : XPBD_E_HIP, "xpbd_world_history_push: %u states of %zu bytes: %s",
                         capacity, slot, hipGetErrorString(e));
-        XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
-        if (w->history_length)
-            XPBD_HIP_TRY(hipMemcpy(bigger.ptr, w->history.ptr, (size_t)w->history_length * slot, hipMemcpyDeviceToDevice));
+        e = hipStreamSynchronize(w->stream);
+        if (e == hipSuccess && w->history_length)
+            e = hipMemcpy(bigger.ptr, w->history.ptr, (size_t)w->history_length * slot, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            bigger.release();
+            return fail(XPBD_E_HIP, "xpbd_world_history_push: carrying %u states over failed: %s", w->history_length, hipGetErrorString(e));
+        }
         w->history.release();
         w->history = bigger;
     }

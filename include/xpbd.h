@@ -88,7 +88,7 @@ typedef struct xpbd_config {
     int32_t  device;       /* HIP device ordinal */
     uint32_t mode;         /* XPBD_MODE_* */
     uint32_t flags;        /* XPBD_FLAG_* */
-    uint32_t block_size;   /* threads per workgroup, multiple of 64; 0 = library default */
+    uint32_t block_size;   /* threads per workgroup, multiple of 64, <= 256; 0 = library default (64) */
     uint32_t reserved[3];  /* must be 0 */
 } xpbd_config;
 
@@ -108,7 +108,8 @@ int  xpbd_world_create(xpbd_world **out, const xpbd_config *cfg);
 void xpbd_world_destroy(xpbd_world *w);
 
 /* Shapes: all shapes' vertices back to back (xyz triples) and a CSR offset
- * array of n_shapes+1 entries (in vertices).  Copied; caller keeps ownership. */
+ * array of n_shapes+1 entries (in vertices).  Copied; caller keeps ownership.
+ * While bodies are resident the new table must still cover every shape id they use (else XPBD_E_INVALID). */
 int  xpbd_world_set_shapes(xpbd_world *w, const double *verts_xyz,
                            const uint32_t *vert_offsets, uint32_t n_shapes);
 
@@ -245,7 +246,8 @@ int  xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *
  * at `distance` (anchors in object space, the space of the shape vertices).  distance = 0 is a ball
  * joint; a hinge is two ball joints on its axis.  Joints are projected in XPBD_MODE_CONTACTS together
  * with the body-body contacts (same Jacobi pass, after a body's contacts, ascending joint index).
- * Body indices refer to the bodies uploaded last; uploading bodies again clears the joints. */
+ * Body indices refer to the bodies uploaded last; uploading bodies again clears the joints.
+ * Only XPBD_MODE_CONTACTS projects joints: in the other modes a non-empty list is XPBD_E_INVALID. */
 typedef struct xpbd_joint {
     uint32_t body_a, body_b;
     double   anchor_a[3];

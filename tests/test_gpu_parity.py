@@ -104,6 +104,21 @@ def test_block_size_does_not_change_results(block_size):
     assert bits_equal(got, want)
 
 
+def test_block_size_above_the_launch_bound_is_rejected():
+    """k_step is compiled with __launch_bounds__(256): 512 used to be accepted and then failed at launch
+    (round-1 gpurun_out/g21/err.log: `unspecified launch failure`).  It is an argument error now."""
+    for bad in (320, 512, 1024, 100):
+        with pytest.raises(capi.XpbdError) as e:
+            capi.World(block_size=bad)
+        assert e.value.code == capi.E_INVALID
+    for mode in MODES:                      # and the largest accepted size runs in both schedules
+        verts, off = capi.scene_shapes(capi.SCENE_BOXES)
+        bodies, sid = capi.scene_generate(capi.SCENE_BOXES, 4, 700)
+        want, _ = ob.step_bodies(bodies, sid, verts, off, DT, 7)
+        got, _, _ = run_world(bodies, sid, verts, off, 7, 1, mode, trace=False, block_size=256)
+        assert bits_equal(got, want)
+
+
 def test_step_one_is_solver_step(oracle):
     import ctypes as C
     verts = ob.polytope("cube").verts()
@@ -208,6 +223,31 @@ def test_argument_errors():
         w.n = 10
         w.step(DT, 4)
         assert w.download().shape == (10, 38)
+        with pytest.raises(capi.XpbdError) as e:        # joints are only projected by the contact pipeline
+            j = np.zeros(1, dtype=capi.JOINT_DTYPE)
+            j["body_b"] = 1
+            w.set_joints(j)
+        assert e.value.code == capi.E_INVALID
+
+
+def test_shrinking_the_shape_table_under_resident_bodies_is_rejected():
+    """The kernels index the staged shape table with the uploaded shape ids unchecked: a smaller table
+    must not be accepted while bodies that name the dropped shapes are resident."""
+    verts, off = capi.scene_shapes(capi.SCENE_MIXED)
+    bodies, sid = capi.scene_generate(capi.SCENE_MIXED, 1, 90)
+    assert sid.max() == 2
+    with capi.World() as w:
+        w.set_shapes(verts, off)
+        w.upload(bodies, sid)
+        with pytest.raises(capi.XpbdError) as e:
+            w.set_shapes(verts[: off[1]], off[:2])
+        assert e.value.code == capi.E_INVALID
+        w.step(DT, 4)                                   # the world is still usable with its old table
+        w.upload(bodies[sid == 0], sid[sid == 0])
+        w.set_shapes(verts[: off[1]], off[:2])          # fine now: only shape 0 is in use
+        w.step(DT, 4)
+        want, _ = ob.step_bodies(bodies[sid == 0], sid[sid == 0], verts, off, DT, 4)
+        assert bits_equal(w.download(), want)
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE sizes)
