@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- body\u00b7substeps/s of the XPBD stepper hot path on N MI355X GPUs of one node.
+"""bench.py -- body·substeps/s of the XPBD stepper hot path on N MI355X GPUs of one node.
 
-A "step" is one frame: xpbd_world_step(dt = 1/60, substeps) over the rank's resident
-bodies, i.e. for every body `solver::step(body, shape, dt, substeps)` (reference
-src/solver.rs:3-17).  Workload at N = 1: BASELINE.json's metric configuration, 262 144
-rigid bodies (unit boxes) x 20 substeps/frame, bodies already resident in HBM (SoA).
+A "step" is one frame: xpbd_world_step(dt = 1/60, substeps) over the rank's resident bodies, i.e. for every
+body `solver::step(body, shape, dt, substeps)` (reference src/solver.rs:3-17).  Workload at N = 1:
+BASELINE.json's metric configuration, 262 144 rigid bodies (unit boxes) x 20 substeps/frame, bodies already
+resident in HBM (SoA).
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL, used only for the
-barrier and the MAX-over-ranks of the wall time).  Bodies never interact in the
-reference, so the world is sharded by contiguous body-index range with NO data-path
-collective; scaling is weak (every rank steps --bodies bodies).
+The timed state does not depend on --warmup / --steps: every scene is first PRE-ROLLED a fixed number of frames
+(PREROLL) into its steady regime -- for `boxes-drop` the bodies have landed and rest / rock on the ground plane with
+~3-4 ground contacts each, the expensive regime -- and only then come the W warm-up and the K timed frames.  The line
+prints the ground contacts per body at the start and at the end of the timed region.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_step) at the
-algorithmic 412 B per body per launch against the 8 TB/s HBM peak;
-`cpu_baseline` times the CPU oracle (C restatement of the reference, single thread like
-the reference) on a bounded sample of the same bodies on this node's host cores.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  On the pinned path bodies never interact
+(reference semantics), so the world is sharded by contiguous body-index range with NO data-path collective; scaling
+is weak (every rank steps --bodies bodies).  The `contacts` sub-results are the north-star workload (body-body
+contacts: the EXTENSION, parity unpinned).
+
+ONE JSON line on rank 0:
+  roofline      the dominant kernel (k_step) at the algorithmic 412 B per body per launch against the
+                8 TB/s HBM peak, plus `peak_measured` = a device-to-device copy by the library's own streaming kernel
+                in this run, and `frac_of_measured`
+  cpu_baseline  the CPU oracle (C restatement of the reference, single thread like the reference) on a bounded sample
+                of the SAME pre-rolled state, median of 3 repeats
+  contacts      {name: {...}} box stacks with SAT contacts (262 144 x 20) and 65 536 mixed polyhedra on the GJK/EPA
+                path, each with its own value, roofline (whole-substep byte model) and cpu_baseline (op_contacts_step)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # BASELINE.json's metric, verbatim (the file travels with the repo; the constant is the fallback)
-METRIC = "body\u00b7substeps/sec at 262k rigid bodies, 20 substeps/frame; 1/2/4/8 GPU"
+METRIC = "body·substeps/sec at 262k rigid bodies, 20 substeps/frame; 1/2/4/8 GPU"
 try:
     with open(os.path.join(ROOT, "BASELINE.json")) as _f:
         METRIC = json.load(_f).get("metric", METRIC)
@@ -34,6 +44,11 @@ except (OSError, ValueError):
     pass
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FRAME_TIME = 1.0 / 60.0  # reference src/app.rs:15
+UNIT = "body·substeps/s"
+# Frames every scene is stepped before anything is timed (independent of --warmup): `*-drop` bodies land after ~0.4 s
+# and have stopped tumbling after ~2 s; the other scenes start in (or next to) contact and settle faster.
+PREROLL = {"boxes-drop": 120, "mixed-drop": 120, "boxes": 60, "mixed": 60, "stacks": 30}
+PREROLL_PILE = 180      # a pile (capi.scene_pile) has fallen and come to rest after ~3 s
 
 
 def reduce_max_seconds(seconds):
@@ -54,84 +69,253 @@ def barrier():
         dist.barrier()
 
 
-def cpu_baseline(state, shape_id, verts, offsets, substeps, budget_s=12.0, sample=8192):
-    """Times the CPU oracle on the first `sample` bodies of the GPU's current state."""
+def timed_frames(step, stream, steps):
+    """EXACTLY `steps` calls of step() bracketed by barrier + synchronize on both sides.
+    Returns (MAX-over-ranks wall seconds, this rank's HIP-event milliseconds on the kernels' stream)."""
+    import torch
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    wall = reduce_max_seconds(time.perf_counter() - t0)
+    return wall, ev0.elapsed_time(ev1)
+
+
+def median_rate(run, units, repeats=3):
+    """run() -> seconds; median over `repeats` of units / seconds, plus the individual rates."""
+    rates = [units / run() for _ in range(repeats)]
+    return statistics.median(rates), rates
+
+
+def cpu_baseline_pinned(state, shape_id, verts, offsets, substeps, budget_s=4.0, sample=8192, repeats=3):
+    """The CPU oracle on the first `sample` bodies of the GPU's pre-rolled state (the state the GPU line is timed on):
+    every repeat starts from that same state, median of `repeats`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     n = min(sample, state.shape[0])
-    bodies, sid = state[:n].copy(), shape_id[:n].copy()
+    start, sid = state[:n].copy(), shape_id[:n].copy()
     t0 = time.perf_counter()
-    bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps)   # calibration frame (also timed)
+    ob.step_bodies(start, sid, verts, offsets, FRAME_TIME, substeps)            # calibration frame
     one = time.perf_counter() - t0
-    frames = int(max(2, min(400, budget_s / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(frames):
-        bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps)
-    sec = time.perf_counter() - t0
-    out = {"value": n * substeps * frames / sec, "unit": "body\u00b7substeps/s", "cores": 1, "kind": "port",
-           "sample": "first %d bodies of the benchmark state after warmup, %d frames x %d substeps, %.1f s, "
-                     "oracle/xpbd_oracle.c (C restatement of the reference, gcc -O2 -ffp-contract=off), 1 thread "
-                     "like the single-threaded reference" % (n, frames, substeps, sec)}
-    # all host cores, for information (the reference itself is single-threaded)
-    cores = min(len(os.sched_getaffinity(0)), 16)        # a 1-GPU box's CPU share is 16 cores
-    if cores > 1:
-        f2 = max(2, frames // 2)
+    frames = int(max(2, min(200, budget_s / max(one, 1e-6))))
+
+    def run(threads=1):
+        bodies = start
         t0 = time.perf_counter()
-        for _ in range(f2):
-            bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps, threads=cores)
-        out["value_all_cores"] = n * substeps * f2 / (time.perf_counter() - t0)
+        for _ in range(frames):
+            bodies, _ = ob.step_bodies(bodies, sid, verts, offsets, FRAME_TIME, substeps, threads=threads)
+        return time.perf_counter() - t0
+
+    value, rates = median_rate(run, n * substeps * frames, repeats)
+    out = {"value": value, "unit": UNIT, "cores": 1, "kind": "port", "repeats": rates,
+           "sample": "first %d bodies of the pre-rolled benchmark state, %d frames x %d substeps per repeat, median of %d, "
+                     "oracle/xpbd_oracle.c (C restatement of the reference, gcc -O2 -ffp-contract=off), 1 thread "
+                     "like the single-threaded reference" % (n, frames, substeps, repeats)}
+    cores = min(len(os.sched_getaffinity(0)), 16)        # a 1-GPU box's CPU share is 16 cores
+    if cores > 1:                                        # for information: the reference itself is single-threaded
+        out["value_all_cores"], _ = median_rate(lambda: run(cores), n * substeps * frames, repeats)
         out["cores_all"] = cores
     return out
 
 
-def run_contacts_sharded(args, capi, kind, rank, local_rank, world_size):
-    """EXTENSION, N > 1: body-body contacts with the world sharded by body-index range; every rank steps
-    owned + ghost bodies and the boundary bodies are exchanged after EVERY substep with one all-gather
-    (RCCL over xGMI under the nccl backend).  Not in the reference; parity = sharded == single device."""
+def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphase, joints, pick, what, budget_s=4.0, repeats=3):
+    """op_contacts_* of the oracle (body-body contact EXTENSION, single thread) on the bodies `pick` (ascending indices)
+    of the GPU's pre-rolled state; joints with both bodies inside the sample are kept."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    import torch
+    import oracle_binding as ob
+    n = len(pick)
+    start, sid = state[pick].copy(), shape_id[pick].copy()
+    polys = ob.polytopes_array(poly_names)
+    if joints is None:
+        joints = np.zeros(0, dtype=[("body_a", "<u4"), ("body_b", "<u4"), ("anchor_a", "<f8", (3,)), ("anchor_b", "<f8", (3,)),
+                                    ("distance", "<f8")])
+    inside = np.isin(joints["body_a"], pick) & np.isin(joints["body_b"], pick)
+    joints = joints[inside].copy()
+    joints["body_a"], joints["body_b"] = np.searchsorted(pick, joints["body_a"]), np.searchsorted(pick, joints["body_b"])
+    t0 = time.perf_counter()
+    ob.contacts_step_joints(start, sid, polys, joints, FRAME_TIME, substeps, pad, narrowphase=narrowphase)
+    one = time.perf_counter() - t0
+    frames = int(max(1, min(50, budget_s / max(one, 1e-6))))
+
+    def run():
+        bodies = start
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            bodies = ob.contacts_step_joints(bodies, sid, polys, joints, FRAME_TIME, substeps, pad, narrowphase=narrowphase)
+        return time.perf_counter() - t0
+
+    value, rates = median_rate(run, n * substeps * frames, repeats)
+    return {"value": value, "unit": UNIT, "cores": 1, "kind": "port", "repeats": rates,
+            "sample": "%d bodies of the pre-rolled state (%s; %d joints), %d frames x %d substeps per repeat, median of %d, "
+                      "oracle/xpbd_pairs_oracle.c op_contacts_* (the build's own CPU definition of the EXTENSION: the "
+                      "reference has no body-body contacts), 1 thread" % (n, what, len(joints), frames, substeps, repeats)}
+
+
+def chain_joints(capi, np, n_joints, count, pitch, grid_w):
+    """BASELINE configs[4] (extension): chains of 5 bodies, 4 distance joints each, centre to centre at the pitch.
+    A chain that would wrap around the end of a grid row loses the joint across the wrap."""
+    k = np.arange(n_joints)
+    a = (k // 4) * 5 + (k % 4)
+    a = a[(a + 1 < count) & (a // grid_w == (a + 1) // grid_w)]
+    joints = np.zeros(len(a), dtype=capi.JOINT_DTYPE)
+    joints["body_a"], joints["body_b"] = a, a + 1
+    joints["anchor_a"], joints["anchor_b"], joints["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], pitch
+    return joints
+
+
+SCENE_KIND = {"boxes": "SCENE_BOXES", "mixed": "SCENE_MIXED", "boxes-drop": "SCENE_BOXES_DROP", "mixed-drop": "SCENE_MIXED_DROP",
+              "stacks": "SCENE_BOX_STACKS"}
+POLY_NAMES = {False: [("cube", 1.0)], True: [("cube", 1.0), ("tetrahedron", 0.5), ("icosahedron", 0.5)]}
+
+
+def contacts_workload(scene, bodies_per_gpu, substeps, narrowphase, joints, pitch, layers):
+    what = "mixed convex polyhedra (cube / tetrahedron / icosahedron)" if "mixed" in scene else "unit boxes"
+    layout = ("dropped as a pile: %d layers of a %.2f m grid, pre-rolled %d frames to rest" % (layers, pitch, PREROLL_PILE)) if layers \
+        else "scene '%s'%s, pre-rolled %d frames" % (scene, "" if pitch == 2.0 else " at %.2f m pitch" % pitch, PREROLL[scene])
+    return ("EXTENSION body-body contacts: %d %s per GPU x %d substeps/frame, dt=1/60, %s, %s narrowphase%s; ground "
+            "contacts as in the reference, pair contacts Jacobi-averaged"
+            % (bodies_per_gpu, what, substeps, layout, "GJK + EPA" if narrowphase == "gjk" else "SAT",
+               ", %d distance joints" % joints if joints else ""))
+
+
+def contacts_scene(capi, args, kind, total, pitch, layers):
+    """All `total` bodies of a contact scene: the seeded grid scene at `pitch`, or (layers > 0) the same bodies as a pile."""
+    if layers:
+        return capi.scene_pile(kind, args.seed, total, pitch, layers)
+    state, shape_id = capi.scene_generate(kind, args.seed, total)
+    if pitch != 2.0:
+        state[:, 31:33] *= pitch / 2.0
+    return state, shape_id
+
+
+def sample_of(np, total, layers, sample):
+    """Indices of a bounded, self-contained sample of a scene: the first `sample` bodies, or -- for a pile -- the same
+    block of grid points in EVERY layer (a pile's bottom layer alone is not a pile)."""
+    if not layers:
+        return np.arange(min(sample, total)), "the first %d bodies" % min(sample, total)
+    per_layer = (total + layers - 1) // layers
+    block = min(sample // layers, per_layer)
+    pick = np.concatenate([np.arange(l * per_layer, min(l * per_layer + block, total)) for l in range(layers)])
+    return pick, "the first %d grid points of each of the %d layers" % (block, layers)
+
+
+def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pitch, rank, local_rank, world_size, steps, warmup,
+                 with_cpu, layers=0):
+    """One contact-pipeline measurement on a world of its own: pre-roll, warm-up, K timed frames.  Returns the result
+    object (rank 0) -- value, roofline of a whole substep, cpu_baseline -- or None."""
+    kind = getattr(capi, SCENE_KIND[scene])
+    total = bodies * world_size
+    pad = 0.02
+    preroll = PREROLL_PILE if layers else PREROLL[scene]
+    if world_size > 1:
+        return run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank,
+                                    local_rank, world_size, steps, warmup)
+    count = total
+    state, shape_id = contacts_scene(capi, args, kind, total, pitch, layers)
+    world = capi.World(device=local_rank, mode=capi.MODE_CONTACTS)
+    world.set_polytopes(capi.scene_polytopes(kind))
+    world.set_contact_pad(pad)
+    world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT)
+    world.upload(state, shape_id)
+    joints = chain_joints(capi, np, joints_n, count, pitch, capi.default_grid_width(total)) if joints_n else None
+    if joints is not None:
+        world.set_joints(joints)
+    stream = torch.cuda.current_stream()
+    world.set_stream(stream.cuda_stream)
+    for _ in range(preroll):
+        world.step(FRAME_TIME, args.substeps)
+    start_state = world.download() if with_cpu else None
+    ground_start = len(world.contacts()) / max(count, 1)
+    for _ in range(warmup):
+        world.step(FRAME_TIME, args.substeps)
+    world.contact_stats()                                      # reset the counters: the stats below cover the timed frames only
+    wall, device_ms = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), stream, steps)
+    result = None
+    if rank == 0:
+        pairs, touching, points = world.contact_stats()
+        n_sub = max(steps * args.substeps, 1)
+        touching_ps, points_ps = touching / n_sub, points / n_sub
+        substep_s = device_ms * 1e-3 / n_sub
+        # Algorithmic bytes of ONE SUBSTEP of the pipeline (narrowphase + the fused per-body kernel), DESIGN.md 8: per body
+        # 716 B (state 13 + 25 doubles, frames in 14 + out 17 doubles, state out 13, shape id), per listed pair 120 B (two
+        # frames, the pair), per touching pair its 24-byte header written once and read by both bodies, per contact point
+        # 48 B written once and read twice.
+        substep_bytes = count * 716 + pairs * 120 + touching_ps * 72 + points_ps * 144
+        achieved = substep_bytes / substep_s / 1e9
+        end_state = world.download()
+        speed = np.linalg.norm(end_state[:, 22:25], axis=1)
+        result = {
+            "value": total * args.substeps * steps / wall, "unit": UNIT, "ms_per_step": wall * 1e3 / steps,
+            "steps": steps, "warmup": warmup, "preroll_frames": preroll,
+            "config": {"workload": contacts_workload(scene, bodies, args.substeps, narrowphase, joints_n, pitch, layers),
+                       "bodies_per_gpu": bodies, "substeps": args.substeps, "scene": scene, "pitch": pitch, "layers": layers,
+                       "narrowphase": narrowphase, "joints": 0 if joints is None else int(len(joints)),
+                       "neighbour_pairs": pairs, "touching_pairs_per_substep": touching_ps,
+                       "manifold_points_per_substep": points_ps,
+                       "ground_contacts_per_body_at_start": ground_start,
+                       "ground_contacts_per_body_at_end": len(world.contacts()) / max(count, 1),
+                       "speed_p50_p99_max_at_end": [float(np.nanpercentile(speed, 50)), float(np.nanpercentile(speed, 99)),
+                                                    float(np.nanmax(speed))],
+                       "extension": "body-body contacts: NOT in the reference (parity unpinned)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "one substep: narrowphase + k_pair_solve_integrate_ground", "launch_us": substep_s * 1e6,
+                         "bytes_per_launch": substep_bytes,
+                         "note": "whole-substep figure from the byte model of DESIGN.md 8 (the narrowphase is f64-VALU / latency "
+                                 "bound, the per-body kernel bandwidth bound; per-kernel times in profiles/)"},
+            "cpu_baseline": None,
+        }
+        if with_cpu:
+            pick, what = sample_of(np, total, layers, 4096)
+            result["cpu_baseline"] = cpu_baseline_contacts(start_state, shape_id, POLY_NAMES["mixed" in scene], args.substeps, pad,
+                                                           1 if narrowphase == "gjk" else 0, joints, pick, what)
+    world.close()
+    return result
+
+
+def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank, local_rank,
+                         world_size, steps, warmup):
+    """EXTENSION, N > 1: body-body contacts with the world sharded by spatial-hash cell; every rank steps owned + ghost
+    bodies and the boundary bodies are exchanged after EVERY substep with one all-gather (RCCL over xGMI under the
+    nccl backend).  Not in the reference; parity = sharded == single device."""
     import torch.distributed as dist
     from constraint_solver_amd.distributed import GpuBackend, ShardedContactWorld
-    total = args.bodies * world_size
-    bodies, shape_id = capi.scene_generate(kind, args.seed, total)
+    total = bodies * world_size
+    state, shape_id = contacts_scene(capi, args, kind, total, pitch, layers)
     polys = capi.scene_polytopes(kind)
     radius = np.array([np.linalg.norm(p["vertices"] - p["centroid"], axis=1).max() for p in polys])
     centroid = np.array([p["centroid"] for p in polys])
     backend = GpuBackend(capi, polys, 0.02, device=local_rank)
-    world = ShardedContactWorld(backend, rank, world_size, bodies, shape_id, radius, centroid, pad=0.02, halo_margin=0.5,
-                                order=args.order)
-    for _ in range(args.warmup):
+    backend.world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT)
+    joints = chain_joints(capi, np, joints_n, total, pitch, capi.default_grid_width(total)) if joints_n else None
+    world = ShardedContactWorld(backend, rank, world_size, state, shape_id, radius, centroid, pad=0.02, halo_margin=0.5,
+                                order=args.order, joints_global=joints)
+    for _ in range(preroll + warmup):
         world.step(FRAME_TIME, args.substeps)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        world.step(FRAME_TIME, args.substeps)
-    torch.cuda.synchronize()
-    barrier()
-    wall = reduce_max_seconds(time.perf_counter() - t0)
+    wall, _ = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), backend.stream, steps)
     result = None
     if rank == 0:
         result = {
-            "metric": METRIC,
-            "value": total * args.substeps * args.steps / wall, "unit": "body\u00b7substeps/s", "n_gpus": world_size,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "EXTENSION body-body contacts: %d unit boxes per GPU x %d substeps/frame, scene '%s'"
-                                   % (args.bodies, args.substeps, args.scene),
-                       "bodies_per_gpu": args.bodies, "bodies_total": total, "substeps": args.substeps, "mode": "contacts",
+            "value": total * args.substeps * steps / wall, "unit": UNIT, "ms_per_step": wall * 1e3 / steps,
+            "steps": steps, "warmup": warmup, "preroll_frames": preroll,
+            "config": {"workload": contacts_workload(scene, bodies, args.substeps, narrowphase, joints_n, pitch, layers),
+                       "bodies_per_gpu": bodies, "bodies_total": total, "substeps": args.substeps, "scene": scene,
                        "order": args.order,
-                       "sharding": "body-index ranges + ghost bodies; halo all-gather after every substep (%s)"
-                                   % dist.get_backend(),
+                       "sharding": "index ranges of the %s body order + ghost bodies; halo all-gather after every substep (%s)"
+                                   % (args.order, dist.get_backend()),
                        "halo_bodies_rank0": int(len(world.plan.ghosts[0])), "boundary_capacity": int(world.plan.capacity),
                        "extension": "not in the reference (parity unpinned; sharded == single device bit for bit)"},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(result), flush=True)
-    barrier()
     backend.close()
-    dist.destroy_process_group()
     return result
 
 
@@ -142,22 +326,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--bodies", type=int, default=262144, help="bodies per GPU (weak scaling)")
     ap.add_argument("--substeps", type=int, default=20)
-    ap.add_argument("--scene", default="boxes-drop", choices=["boxes", "mixed", "boxes-drop", "mixed-drop", "stacks"])
+    ap.add_argument("--scene", default="boxes-drop", choices=sorted(SCENE_KIND))
     ap.add_argument("--mode", default="fused", choices=["fused", "substep", "contacts"],
                     help="contacts = EXTENSION (body-body contacts; not in the reference, parity unpinned)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the informational extra measurements (unfused roofline, PCIe-inclusive); for profiling runs")
+                    help="skip the informational extra measurements (unfused roofline, HBM-resident size, PCIe-inclusive)")
+    ap.add_argument("--no-contacts", action="store_true",
+                    help="skip the `contacts` sub-results of the default run (box stacks with SAT contacts, mixed polyhedra on GJK/EPA)")
+    ap.add_argument("--only", default="", help="profiling aid: run ONLY this part ('pinned', or a contacts sub-result name) "
+                                               "with no extras and no CPU leg")
     ap.add_argument("--narrowphase", default="sat", choices=["sat", "gjk"],
                     help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (one point per pair)")
     ap.add_argument("--joints", type=int, default=0,
                     help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
-    ap.add_argument("--order", default="index", choices=["index", "spatial"],
+    ap.add_argument("--order", default="spatial", choices=["index", "spatial"],
                     help="contacts mode, N > 1: shard the caller's index ranges, or renumber bodies by grid cell first")
     ap.add_argument("--pitch", type=float, default=2.0,
                     help="grid pitch of the scene in metres (generator default 2.0); < 2 packs bodies so that they collide")
+    ap.add_argument("--layers", type=int, default=0,
+                    help="contacts mode: drop the scene's bodies as a pile of this many grid layers (capi.scene_pile)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier/MAX reduction (gloo: rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
@@ -192,9 +382,51 @@ def main():
     from constraint_solver_amd import capi
     from constraint_solver_amd.sharding import shard_range
 
-    kind = {"boxes": capi.SCENE_BOXES, "mixed": capi.SCENE_MIXED, "boxes-drop": capi.SCENE_BOXES_DROP,
-            "mixed-drop": capi.SCENE_MIXED_DROP, "stacks": capi.SCENE_BOX_STACKS}[args.scene]
-    mode = {"fused": capi.MODE_FUSED, "substep": capi.MODE_PER_SUBSTEP, "contacts": capi.MODE_CONTACTS}[args.mode]
+    # Everything runs on an explicit torch stream so torch.cuda.Event (HIP events) brackets OUR launches; the
+    # default stream's handle is 0, which the ABI reads as "use the world's own stream".
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    with_cpu = world_size == 1 and not args.no_cpu_baseline and not args.only
+
+    # the contacts sub-results of the default line: the north-star workloads (BASELINE.json configs[3] size with SAT
+    # box stacks; configs[2]: 65 536 mixed convex polyhedra on the GJK/EPA path)
+    sub_runs = {
+        "stacks_262144_sat": dict(scene="stacks", bodies=262144, narrowphase="sat", joints_n=0, pitch=2.0),
+        "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4),
+        "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4),
+        "boxes_262144_joints_65536": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=65536, pitch=2.0),
+    }
+    if args.only and args.only != "pinned":
+        if args.only not in sub_runs:
+            raise SystemExit("--only: one of pinned, %s" % ", ".join(sub_runs))
+        r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size, steps=args.steps,
+                         warmup=args.warmup, with_cpu=False, **sub_runs[args.only])
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "n_gpus": world_size, **r}), flush=True)
+        barrier()
+        if world_size > 1:
+            dist.destroy_process_group()
+        return r
+
+    if args.mode == "contacts":
+        r = run_contacts(capi, np, torch, args, args.scene, args.bodies, args.narrowphase, args.joints, args.pitch, rank, local_rank,
+                         world_size, args.steps, args.warmup, with_cpu, layers=args.layers)
+        result = None
+        if rank == 0:
+            result = {"metric": METRIC, "value": r["value"], "unit": UNIT, "n_gpus": world_size, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": r["config"], "roofline": r["roofline"],
+                      "cpu_baseline": r["cpu_baseline"], "preroll_frames": r["preroll_frames"]}
+            print(json.dumps(result), flush=True)
+        barrier()
+        if world_size > 1:
+            dist.destroy_process_group()
+        return result
+
+    # ---------------------------------------------------------------- the pinned path (reference semantics)
+    kind = getattr(capi, SCENE_KIND[args.scene])
+    mode = {"fused": capi.MODE_FUSED, "substep": capi.MODE_PER_SUBSTEP}[args.mode]
     total = args.bodies * world_size
     first, count = shard_range(total, rank, world_size)
     verts, offsets = capi.scene_shapes(kind)
@@ -202,127 +434,113 @@ def main():
     if args.pitch != 2.0:
         bodies[:, 31:33] *= args.pitch / 2.0
 
-    if mode == capi.MODE_CONTACTS and world_size > 1:
-        return run_contacts_sharded(args, capi, kind, rank, local_rank, world_size)
-
+    # Pre-roll into the steady regime on a world of its own, created with the contact trace on: that instantiates the
+    # stepper as k_step<true>, so in a rocprofv3 kernel trace of this command the k_step<false> rows are exactly the
+    # warm-up and timed launches below (same arithmetic, same bits; the trace only adds the mask stores).
+    with capi.World(device=local_rank, mode=capi.MODE_FUSED, trace_contacts=True) as pre:
+        pre.set_shapes(verts, offsets)
+        pre.upload(bodies, shape_id)
+        for _ in range(PREROLL[args.scene]):
+            pre.step(FRAME_TIME, args.substeps)
+        start_state = pre.download()
     world = capi.World(device=local_rank, mode=mode, block_size=args.block_size)
-    if mode == capi.MODE_CONTACTS:
-        world.set_polytopes(capi.scene_polytopes(kind))
-        world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if args.narrowphase == "gjk" else capi.NARROWPHASE_SAT)
-    else:
-        world.set_shapes(verts, offsets)
-    world.upload(bodies, shape_id)                       # inputs resident in HBM before any timing
-    if args.joints and mode == capi.MODE_CONTACTS:
-        # BASELINE configs[4] (extension): chains of 5 bodies, 4 distance joints each, centre to centre at the pitch
-        k = np.arange(args.joints)
-        a = (k // 4) * 5 + (k % 4)
-        a = a[a + 1 < count]
-        joints = np.zeros(len(a), dtype=capi.JOINT_DTYPE)
-        joints["body_a"], joints["body_b"] = a, a + 1
-        joints["anchor_a"], joints["anchor_b"], joints["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], args.pitch
-        world.set_joints(joints)
-    # Run on an explicit torch stream so torch.cuda.Event (HIP events) brackets OUR launches; the
-    # default stream's handle is 0, which the ABI reads as "use the world's own stream".
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
+    world.set_shapes(verts, offsets)
+    world.upload(start_state, shape_id)                  # inputs resident in HBM before any timing
     world.set_stream(stream.cuda_stream)
-
+    world.step(FRAME_TIME, args.substeps)                # (one untimed frame so that the contact list below exists)
+    contacts_start = len(world.contacts()) / max(count, 1)
     for _ in range(args.warmup):
         world.step(FRAME_TIME, args.substeps)
-    torch.cuda.synchronize()
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        world.step(FRAME_TIME, args.substeps)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
-    wall = reduce_max_seconds(wall)
-    device_ms = ev0.elapsed_time(ev1)                    # HIP events on the kernels' stream
+    wall, device_ms = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), stream, args.steps)
 
     result = None
     if rank == 0:
-        launches_per_step = 1 if mode == capi.MODE_FUSED else args.substeps   # contacts: 3 kernels per substep
+        launches_per_step = 1 if mode == capi.MODE_FUSED else args.substeps
         launch_s = device_ms * 1e-3 / (args.steps * launches_per_step)
         bytes_per_launch = capi.BYTES_PER_BODY_SUBSTEP * count   # 412 B x bodies, fused or not
         achieved = bytes_per_launch / launch_s / 1e9
-        traffic = None
+        traffic, traffic_note = None, None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            key = "%s_%d" % (args.mode, count)
-            traffic = json.load(open(tfile)).get(key, {}).get("bytes_per_launch")
+        if os.path.exists(tfile):                        # PMC counters cannot be read from inside the run: the figure is the
+            entry = json.load(open(tfile)).get("%s_%d" % (args.mode, count), {})   # committed rocprofv3 --pmc pass of this
+            traffic, traffic_note = entry.get("bytes_per_launch"), entry.get("source")        # same configuration
         result = {
             "metric": METRIC,
             "value": total * args.substeps * args.steps / wall,
-            "unit": "body\u00b7substeps/s",
+            "unit": UNIT,
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d %s per GPU x %d substeps/frame, dt=1/60, ground contacts "
-                                   "(reference semantics), seeded scene '%s'"
+            "config": {"workload": "%d %s per GPU x %d substeps/frame, dt=1/60, ground contacts (reference semantics: bodies "
+                                   "do not interact), seeded scene '%s' pre-rolled %d frames into resting contact"
                                    % (args.bodies, "mixed convex polyhedra" if "mixed" in args.scene else "unit boxes",
-                                      args.substeps, args.scene),
+                                      args.substeps, args.scene, PREROLL[args.scene]),
                        "bodies_per_gpu": args.bodies, "bodies_total": total, "substeps": args.substeps,
-                       "mode": args.mode, "sharding": "contiguous body-index ranges, no data-path collective"},
+                       "mode": args.mode, "preroll_frames": PREROLL[args.scene],
+                       "ground_contacts_per_body_at_start": contacts_start,
+                       "ground_contacts_per_body_at_end": len(world.contacts()) / max(count, 1),
+                       "sharding": "contiguous body-index ranges, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "k_step", "launch_us": launch_s * 1e6, "bytes_per_launch": bytes_per_launch,
                          "note": ("fused: all %d substeps of a body run in registers, so one launch moves 412 B/body "
                                   "once and the kernel is f64-VALU bound, not HBM bound" % args.substeps)
                          if mode == capi.MODE_FUSED else "one launch per substep: state round-trips HBM every substep"},
         }
-        result["config"]["ground_contacts_per_body_after_run"] = len(world.contacts()) / max(count, 1)
-        if mode == capi.MODE_CONTACTS:
-            pairs, touching, points = world.contact_stats()
-            all_substeps = max((args.steps + args.warmup) * args.substeps, 1)
-            touching_per_substep, points_per_substep = touching / all_substeps, points / all_substeps
-            result["config"]["extension"] = "body-body contacts: NOT in the reference (parity unpinned)"
-            result["config"]["joints"] = args.joints
-            result["config"]["narrowphase"] = args.narrowphase
-            result["config"]["neighbour_pairs"] = pairs
-            result["config"]["touching_pairs_per_substep"] = touching_per_substep
-            result["config"]["manifold_points_per_substep"] = points_per_substep
-            # Algorithmic bytes of ONE SUBSTEP of the pipeline (narrowphase + the fused per-body kernel), DESIGN.md 8:
-            # per body 716 B (state 13 + 25 doubles, frames in 14 + out 17 doubles, state out 13, shape id), per listed
-            # pair 120 B (two frames, the pair), per touching pair its 24-byte header written once and read by both
-            # bodies, per contact point 48 B written once and read twice.
-            substep_bytes = count * 716 + pairs * 120 + touching_per_substep * 72 + points_per_substep * 144
-            result["roofline"].update({
-                "achieved": substep_bytes / launch_s / 1e9, "frac": substep_bytes / launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "one substep: narrowphase + k_pair_solve_integrate_ground", "bytes_per_launch": substep_bytes,
-                "note": "whole-substep figure (the SAT is f64-VALU / latency bound, the per-body kernel bandwidth bound; "
-                        "per-kernel times in profiles/r01_o_contacts_*_kernel_stats.csv)"})
-        if world_size == 1 and mode == capi.MODE_FUSED and not args.no_extras:
+        extras = world_size == 1 and not args.no_extras and not args.only
+        if extras:
+            # The HBM roof as measured in THIS run: device-to-device copy of 2 GiB (8x the 256 MiB Infinity Cache) by the
+            # library's own streaming kernel ("HBM_peak both nominal and measured").
+            measured = capi.selftest_hbm_copy(1 << 31, 10, device=local_rank)
+            result["roofline"]["peak_measured"] = measured
+            result["roofline"]["frac_of_measured"] = achieved / measured
+        if extras and mode == capi.MODE_FUSED:
             # The same kernel scheduled one launch per substep (state round-trips HBM every substep):
             # the HBM-roofline-comparable form, measured in the same run on the same resident state.
             frames = max(3, min(10, args.steps))
             world.set_mode(capi.MODE_PER_SUBSTEP)
             for _ in range(2):
                 world.step(FRAME_TIME, args.substeps)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(frames):
-                world.step(FRAME_TIME, args.substeps)
-            e1.record(stream)
-            torch.cuda.synchronize()
+            _, ms = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), stream, frames)
             world.set_mode(capi.MODE_FUSED)
-            sub_s = e0.elapsed_time(e1) * 1e-3 / (frames * args.substeps)
+            sub_s = ms * 1e-3 / (frames * args.substeps)
             tr = None
             if os.path.exists(tfile):
                 tr = json.load(open(tfile)).get("substep_%d" % count, {}).get("bytes_per_launch")
-            result["roofline_unfused"] = {"bound": "hbm", "achieved": bytes_per_launch / sub_s / 1e9, "peak": HBM_PEAK_GBPS,
-                                          "unit": "GB/s", "frac": bytes_per_launch / sub_s / 1e9 / HBM_PEAK_GBPS,
+            ach = bytes_per_launch / sub_s / 1e9
+            result["roofline_unfused"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": ach / HBM_PEAK_GBPS, "peak_measured": measured, "frac_of_measured": ach / measured,
                                           "traffic": tr, "kernel": "k_step", "launch_us": sub_s * 1e6,
                                           "body_substeps_per_s": count / sub_s,
-                                          "note": "XPBD_MODE_PER_SUBSTEP: one launch per substep, 412 B per body per launch"}
-        if world_size == 1 and not args.no_extras:
+                                          "note": "XPBD_MODE_PER_SUBSTEP: one launch per substep, 412 B per body per launch; the "
+                                                  "108 MB working set fits the 256 MiB Infinity Cache (see roofline_hbm_resident)"}
+            # ... and at a size that does NOT fit the Infinity Cache: 2 097 152 bodies = 864 MB of state per launch
+            big_n = 1 << 21
+            big_bodies, big_sid = capi.scene_generate(kind, args.seed, big_n)
+            with capi.World(device=local_rank, mode=capi.MODE_FUSED) as big:
+                big.set_shapes(verts, offsets)
+                big.upload(big_bodies, big_sid)
+                del big_bodies
+                big.set_stream(stream.cuda_stream)
+                for _ in range(PREROLL[args.scene]):
+                    big.step(FRAME_TIME, args.substeps)
+                big.set_mode(capi.MODE_PER_SUBSTEP)
+                big.step(FRAME_TIME, args.substeps)
+                _, ms = timed_frames(lambda: big.step(FRAME_TIME, args.substeps), stream, 5)
+                big_s = ms * 1e-3 / (5 * args.substeps)
+                big_bytes = capi.BYTES_PER_BODY_SUBSTEP * big_n
+                big_contacts = len(big.contacts()) / big_n
+            ach = big_bytes / big_s / 1e9
+            big_tr = json.load(open(tfile)).get("substep_%d" % big_n, {}).get("bytes_per_launch") if os.path.exists(tfile) else None
+            result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                               "frac": ach / HBM_PEAK_GBPS, "peak_measured": measured, "frac_of_measured": ach / measured,
+                                               "traffic": big_tr, "kernel": "k_step", "launch_us": big_s * 1e6, "bodies": big_n,
+                                               "bytes_per_launch": big_bytes, "body_substeps_per_s": big_n / big_s,
+                                               "ground_contacts_per_body": big_contacts,
+                                               "note": "XPBD_MODE_PER_SUBSTEP at 2 097 152 bodies: 864 MB per launch, 3.4x the "
+                                                       "Infinity Cache, so this one IS an HBM number"}
+        if extras:
             # Informational, never `value`: the same frame when the boundary hands over HOST buffers
             # (AoS upload over PCIe -> step -> AoS download), as a literal per-frame drop-in would.
             state = world.download()
@@ -332,7 +550,7 @@ def main():
                 world.step(FRAME_TIME, args.substeps)
                 state = world.download()
             per_frame = (time.perf_counter() - t0) / 3
-            result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": "body\u00b7substeps/s",
+            result["pcie_inclusive"] = {"value": count * args.substeps / per_frame, "unit": UNIT,
                                         "ms_per_frame": per_frame * 1e3,
                                         "what": "pageable host AoS upload + step + download every frame"}
             # What the reference's app actually needs per frame: state stays resident, only Rigid::frame() of every
@@ -342,15 +560,26 @@ def main():
                 world.step(FRAME_TIME, args.substeps)
                 world.frames()
             per_frame = (time.perf_counter() - t0) / 5
-            result["render_readback"] = {"value": count * args.substeps / per_frame, "unit": "body\u00b7substeps/s",
+            result["render_readback"] = {"value": count * args.substeps / per_frame, "unit": UNIT,
                                          "ms_per_frame": per_frame * 1e3,
                                          "what": "step + download of Rigid::frame() (56 B/body) every frame"}
-        if world_size == 1 and not args.no_cpu_baseline and mode != capi.MODE_CONTACTS:
-            state = world.download()
-            result["cpu_baseline"] = cpu_baseline(state, shape_id, verts, offsets, args.substeps)
+        if with_cpu:
+            result["cpu_baseline"] = cpu_baseline_pinned(start_state, shape_id, verts, offsets, args.substeps)
+    world.close()
+
+    # ---------------------------------------------------------------- the north-star workloads (extension)
+    if not args.no_contacts and not args.only and mode == capi.MODE_FUSED:
+        subs = {}
+        for name, cfg in sub_runs.items():
+            r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
+                             steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, **cfg)
+            if rank == 0:
+                subs[name] = r
+        if rank == 0:
+            result["contacts"] = subs
+    if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()
-    world.close()
     if world_size > 1:
         dist.destroy_process_group()
     return result

@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_import_dynamic_rows", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
     "xpbd_world_set_sat_schedule",
+    "xpbd_selftest_hbm_copy",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
 
@@ -122,6 +123,7 @@ def hip_lib():
         L.xpbd_world_set_mode.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_step_one.argtypes = [C.c_void_p, _f64p, C.c_uint32, C.c_double, C.c_uint32]
         L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
+        L.xpbd_selftest_hbm_copy.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, _f64p]
         L.xpbd_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
         L.xpbd_world_narrowphase.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         L.xpbd_world_narrowphase_gjk.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
@@ -368,6 +370,13 @@ def selftest_div_sqrt(a, b, device=0):
     return q, s
 
 
+def selftest_hbm_copy(nbytes=1 << 31, repeats=10, device=0):
+    """GB/s (read + written) of a device-to-device copy by the library's streaming kernel: the measured HBM roof."""
+    out = C.c_double(0.0)
+    _check(hip_lib().xpbd_selftest_hbm_copy(device, nbytes, repeats, C.byref(out)))
+    return out.value
+
+
 # ---- host mirror (CPU set-up math; no GPU needed) -------------------------------
 SAT_SCHEDULE_AUTO, SAT_SCHEDULE_ONE_PASS, SAT_SCHEDULE_TWO_PASS = 0, 1, 2
 SCENE_BOXES, SCENE_MIXED, SCENE_BOXES_DROP, SCENE_MIXED_DROP, SCENE_BOX_STACKS = 0, 1, 2, 3, 4
@@ -397,6 +406,27 @@ def scene_generate(kind, seed, n, first=0, count=None, grid_w=None):
     rc = host_lib().xpbdh_scene_generate(kind, seed, grid_w, first, count, bodies.ctypes.data, _u32(sid))
     if rc != OK:
         raise XpbdError(rc, "scene generation failed")
+    return bodies, sid
+
+
+def scene_pile(kind, seed, n, pitch, layers, layer_gap=2.5, lift=0.6):
+    """The seeded scene re-gridded into a PILE for the body-body contact extension: `layers` layers of a square grid at
+    `pitch` metres, `layer_gap` metres apart, the CENTRES OF MASS on the grid points (world centre = position +
+    center_of_mass whatever the rotation, src/rigid.rs:75-80; the shapes' origins are a corner for the cube and the
+    tetrahedron and the centre for the icosahedron), heights lifted by `lift`.  With the defaults nothing overlaps at
+    t = 0: cube radius 0.866 about its centre, half-size tetrahedron 0.42, icosahedron 0.5; the generator's heights jitter by
+    0.6 m; the mixed grid never puts two cubes side by side when the grid width is not a multiple of 3 (shape = index
+    mod 3) and pitch >= 1.4 keeps a cube clear of the smaller shapes; boxes need pitch >= 1.75.  A scene with deep
+    initial overlaps is resolved in ONE substep (XPBD has no velocity clamp), i.e. depth / h = 120 m/s for 0.1 m, and
+    never reaches a steady contact regime."""
+    bodies, sid = scene_generate(kind, seed, n)
+    per_layer = (n + layers - 1) // layers
+    w = default_grid_width(per_layer)
+    i = np.arange(n)
+    k = i % per_layer
+    bodies[:, 31] = pitch * (k % w) - bodies[:, 28]
+    bodies[:, 32] = pitch * (k // w) - bodies[:, 29]
+    bodies[:, 33] += lift + layer_gap * (i // per_layer) + (0.5 - bodies[:, 30])
     return bodies, sid
 
 

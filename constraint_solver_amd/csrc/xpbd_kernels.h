@@ -71,6 +71,11 @@ hipError_t launch_contacts_count(const uint32_t *mask, uint32_t n, uint32_t *blo
 hipError_t launch_contacts_emit(const uint32_t *mask, uint32_t n, const uint32_t *block_counts,
                                 xpbd_contact *out, uint32_t cap, hipStream_t stream);
 
+// Device-to-device copy of `bytes` (multiple of 16, < 2^40) with one of the library's streaming kernels:
+// variant 0 / 1 one 16-byte element per lane (plain / non-temporal), 2 / 3 grid-stride with four loads in flight.
+constexpr uint32_t kCopyVariants = 4;
+hipError_t launch_copy16(const void *src, void *dst, size_t bytes, uint32_t variant, hipStream_t stream);
+
 // Diagnostics: q = a / b, r = sqrt(a), element-wise, all device pointers.
 hipError_t launch_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, uint32_t n,
                                     hipStream_t stream);

@@ -223,6 +223,48 @@ __global__ void k_selftest_div_sqrt(const double *__restrict__ a, const double *
     }
 }
 
+// Device-to-device copy kernels: the measured HBM roof the stepper's achieved bandwidth is priced against
+// (xpbd_selftest_hbm_copy reports the fastest variant).  16 bytes per lane and access; ONE element per lane with a
+// grid as large as the buffer, or grid-stride with four independent loads in flight per lane; plain or non-temporal
+// accesses (every byte is touched once).
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ v4f copy_load(const v4f *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void copy_store(v4f *p, v4f v)
+{
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) k_copy16_flat(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n16)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n16)
+        copy_store<NT>(dst + k, copy_load<NT>(src + k));
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) k_copy16_strided(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k + 3 * stride < n16; k += 4 * stride) {
+        v4f v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = copy_load<NT>(src + k + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            copy_store<NT>(dst + k + u * stride, v[u]);
+    }
+    for (; k < n16; k += stride)
+        dst[k] = src[k];
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -276,6 +318,23 @@ hipError_t launch_contacts_emit(const uint32_t *mask, uint32_t n, const uint32_t
     const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
     if (nb)
         hipLaunchKernelGGL(k_contacts_emit, dim3(nb), dim3(kScanBlock), 0, stream, mask, n, block_counts, out, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy16(const void *src, void *dst, size_t bytes, uint32_t variant, hipStream_t stream)
+{
+    const size_t n16 = bytes / 16;
+    if (n16 == 0)
+        return hipSuccess;
+    const v4f *s = static_cast<const v4f *>(src);
+    v4f *d = static_cast<v4f *>(dst);
+    const dim3 flat((uint32_t)((n16 + 255) / 256)), strided(2048); // strided: 256 CUs x 8 workgroups of 4 waves
+    switch (variant % kCopyVariants) {
+    case 0: hipLaunchKernelGGL(k_copy16_flat<false>, flat, dim3(256), 0, stream, s, d, n16); break;
+    case 1: hipLaunchKernelGGL(k_copy16_flat<true>, flat, dim3(256), 0, stream, s, d, n16); break;
+    case 2: hipLaunchKernelGGL(k_copy16_strided<false>, strided, dim3(256), 0, stream, s, d, n16); break;
+    default: hipLaunchKernelGGL(k_copy16_strided<true>, strided, dim3(256), 0, stream, s, d, n16); break;
+    }
     return hipGetLastError();
 }
 

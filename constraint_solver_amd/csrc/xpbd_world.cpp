@@ -1175,4 +1175,43 @@ int xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b, dou
     return XPBD_OK;
 }
 
+int xpbd_selftest_hbm_copy(int32_t device, uint64_t bytes, uint32_t repeats, double *gbytes_per_s)
+{
+    if (!gbytes_per_s || bytes < 16 || bytes >= (1ull << 40) || repeats == 0)
+        return fail(XPBD_E_INVALID, "xpbd_selftest_hbm_copy: bad argument");
+    *gbytes_per_s = 0.0;
+    XPBD_HIP_TRY(hipSetDevice(device));
+    bytes &= ~(uint64_t)15;
+    DeviceBuffer src, dst;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = src.reserve(bytes);
+    if (e == hipSuccess) e = dst.reserve(bytes);
+    if (e == hipSuccess) e = hipMemset(src.ptr, 0x3c, bytes);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best_ms = 0.0f;
+    for (uint32_t variant = 0; variant < xpbd::kCopyVariants && e == hipSuccess; ++variant) { // report the fastest kernel
+        const uint32_t nt = variant;
+        e = xpbd::launch_copy16(src.ptr, dst.ptr, bytes, nt, nullptr); // warm-up (page tables, clocks)
+        if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+        for (uint32_t k = 0; k < repeats && e == hipSuccess; ++k)
+            e = xpbd::launch_copy16(src.ptr, dst.ptr, bytes, nt, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && (variant == 0 || ms < best_ms))
+            best_ms = ms;
+    }
+    const float ms = best_ms;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    src.release();
+    dst.release();
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? XPBD_E_OOM : XPBD_E_HIP, "xpbd_selftest_hbm_copy: %s", hipGetErrorString(e));
+    *gbytes_per_s = 2.0 * (double)bytes * repeats / ((double)ms * 1e-3) / 1e9; // bytes read + bytes written
+    return XPBD_OK;
+}
+
 } // extern "C"

@@ -294,6 +294,11 @@ uint32_t xpbd_world_history_length(const xpbd_world *w);
 int  xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b,
                             double *quotient, double *root, uint32_t n);
 
+/* Diagnostics: the HBM roof as this library can reach it -- a device-to-device copy of `bytes` (use far more than the
+ * 256 MiB Infinity Cache) by the library's own streaming kernel, `repeats` launches timed with HIP events.
+ * *gbytes_per_s = (bytes read + bytes written) / time, in 1e9 bytes per second. */
+int  xpbd_selftest_hbm_copy(int32_t device, uint64_t bytes, uint32_t repeats, double *gbytes_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,30 +1,55 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): bench lines, rocprofv3 kernel-trace stats and the PMC
-# passes for k_step, each counter group in its own run (never mixed with other trace domains).
-# Usage: scripts/gpu_profile.sh <tag>      -> everything lands under gpurun_out/<tag>/
+# Runs on the GPU box (through gpurun): the bench line with the DRIVER'S arguments, rocprofv3 kernel-trace stats of the
+# same command restricted to one part at a time (--only: no extras / CPU leg, so the kernel rows are the timed regime),
+# and the PMC passes, each counter group in its own run (never mixed with other trace domains).
+# Usage: scripts/gpu_profile.sh <tag> [parts...]   -> everything lands under gpurun_out/<tag>/
+#   parts: bench trace pmc pmc_big contacts_pmc  (default: bench trace pmc)
 set -eo pipefail
-TAG=${1:-prof}
+TAG=${1:-prof}; shift || true
+PARTS=${*:-bench trace pmc}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="python3 bench.py --warmup 40 --no-cpu-baseline --no-extras"
+B="python3 bench.py --steps 20 --warmup 5"     # what the driver runs at round end
 
-timeout -k 10 300 python3 bench.py --steps 60 --warmup 30 > "$OUT/bench_fused.json" 2> "$OUT/bench_fused.err"
-timeout -k 10 300 $B --steps 30 --mode substep > "$OUT/bench_substep.json" 2> "$OUT/bench_substep.err"
-timeout -k 10 300 $B --steps 30 --scene mixed-drop --bodies 65536 > "$OUT/bench_mixed65536.json" 2> "$OUT/bench_mixed.err"
-
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_fused" -- $B --steps 20 > "$OUT/trace_fused.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_substep" -- $B --steps 10 --mode substep > "$OUT/trace_substep.log" 2>&1
-
-pmc() { # name, mode-args, counters...
-  local name=$1 extra=$2; shift 2
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $B --steps 5 $extra > "$OUT/pmc_$name.log" 2>&1
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+trace() { # name, extra args
+  local name=$1; shift
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$name" -- $B "$@" > "$OUT/trace_$name.log" 2>&1
 }
-pmc valu "" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
-pmc wave "" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
-pmc fetch_fused "" FETCH_SIZE
-pmc write_fused "" WRITE_SIZE
-pmc fetch_substep "--mode substep" FETCH_SIZE
-pmc write_substep "--mode substep" WRITE_SIZE
+pmc() { # name, "extra args", counters...
+  local name=$1 extra=$2; shift 2
+  timeout -k 10 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $B $extra > "$OUT/pmc_$name.log" 2>&1
+}
+
+if has bench; then
+  timeout -k 10 600 $B > "$OUT/bench.json" 2> "$OUT/bench.err"
+fi
+if has trace; then
+  trace pinned --only pinned
+  trace pinned_substep --only pinned --mode substep
+  trace stacks --only stacks_262144_sat
+  trace mixed_gjk --only mixed_pile_65536_gjk_epa
+  trace mixed_sat --only mixed_pile_65536_sat
+  trace joints --only boxes_262144_joints_65536
+fi
+if has pmc; then
+  pmc valu "--only pinned" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
+  pmc wave "--only pinned" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+  pmc fetch_fused "--only pinned" FETCH_SIZE
+  pmc write_fused "--only pinned" WRITE_SIZE
+  pmc fetch_substep "--only pinned --mode substep" FETCH_SIZE
+  pmc write_substep "--only pinned --mode substep" WRITE_SIZE
+fi
+if has pmc_big; then   # 2 097 152 bodies: 864 MB per launch, far beyond the 256 MiB Infinity Cache
+  pmc fetch_substep_big "--only pinned --mode substep --bodies 2097152 --steps 5 --warmup 2" FETCH_SIZE
+  pmc write_substep_big "--only pinned --mode substep --bodies 2097152 --steps 5 --warmup 2" WRITE_SIZE
+fi
+if has contacts_pmc; then
+  pmc fetch_stacks "--only stacks_262144_sat" FETCH_SIZE
+  pmc write_stacks "--only stacks_262144_sat" WRITE_SIZE
+  pmc fetch_mixed_sat "--only mixed_pile_65536_sat" FETCH_SIZE
+  pmc write_mixed_sat "--only mixed_pile_65536_sat" WRITE_SIZE
+fi
 python3 scripts/summarize_profile.py "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"

@@ -1,90 +1,136 @@
 #!/usr/bin/env python3
-"""Condenses one scripts/gpu_profile.sh output directory into a JSON summary (the file that is
-copied to profiles/ and committed).  Per-launch figures are averages over the LAST dispatches of
-k_step in each run, i.e. the timed region where the boxes rest on the plane.
+"""Condenses one scripts/gpu_profile.sh output directory into a JSON summary (the file that is copied to profiles/ and
+committed) and copies every trace's kernel_stats.csv next to it as <tag>_<trace>_kernel_stats.csv.
 
-HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
-WRITE_SIZE are KiB, collected in separate passes; on gfx950 FETCH_SIZE reports exactly half the
-bytes of a coalesced streaming read, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The
-factor is confirmed in place: 2 x FETCH_SIZE reproduces the kernel's known read set
-(308 B/body) to within 0.3 %.
-"""
+Per kernel and trace: calls, average / min / max duration (rocprofv3 --stats) and the average over the LAST `tail`
+dispatches of the kernel trace (= the timed region: the runs use bench.py --only <part>, whose last launches are the K
+timed frames).  PMC: averages over the last dispatches of each kernel.
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are KiB, collected in
+separate passes; on gfx950 FETCH_SIZE reports exactly half the bytes of a coalesced streaming read, so
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (confirmed in place on k_step: 2 x FETCH_SIZE reproduces its known read
+set of 308 B/body to 0.3 %).  For gather-heavy kernels the factor is uncalibrated (the guide says so): those rows are
+labelled `uncalibrated` and are to be read as ratios between variants."""
 import collections
 import csv
 import glob
 import json
 import os
+import shutil
 import sys
 
 
-def rows_of(pattern):
+def newest(pattern):
     files = glob.glob(pattern, recursive=True)
-    # a directory can hold several runs: take the newest
-    return list(csv.DictReader(open(max(files, key=os.path.getmtime)))) if files else []
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def rows_of(pattern):
+    f = newest(pattern)
+    return list(csv.DictReader(open(f))) if f else []
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").replace("xpbd::", "").split("(")[0].strip()
+
+
+def trace_summary(out, name, steps=20, substeps=20):
+    res = {}
+    for r in rows_of(os.path.join(out, "trace_" + name, "**", "*_kernel_stats.csv")):
+        res[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                 "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])}
+    per_kernel = collections.defaultdict(list)
+    for r in rows_of(os.path.join(out, "trace_" + name, "**", "*_kernel_trace.csv")):
+        per_kernel[short(r["Kernel_Name"])].append(r)
+    for k, rows in per_kernel.items():
+        if k not in res:
+            continue
+        tail = rows[-min(len(rows), steps * substeps if len(rows) >= steps * substeps else steps):]
+        res[k]["timed_region_avg_us"] = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail) / len(tail) / 1e3
+        res[k]["timed_region_dispatches"] = len(tail)
+        res[k]["vgprs"] = int(rows[-1].get("VGPR_Count", 0) or 0)
+        res[k]["lds_bytes"] = int(rows[-1].get("LDS_Block_Size", 0) or 0)
+        res[k]["workgroup"] = int(rows[-1]["Workgroup_Size_X"])
+        res[k]["grid"] = int(rows[-1]["Grid_Size_X"])
+    return res
 
 
 def pmc(out, name, last):
-    rows = [r for r in rows_of(os.path.join(out, "pmc_" + name, "**", "*_counter_collection.csv")) if "k_step" in r["Kernel_Name"]]
-    ids = sorted(set(int(r["Dispatch_Id"]) for r in rows))[-last:]
-    acc = collections.defaultdict(float)
+    rows = rows_of(os.path.join(out, "pmc_" + name, "**", "*_counter_collection.csv"))
+    per_kernel = collections.defaultdict(list)
     for r in rows:
-        if int(r["Dispatch_Id"]) in ids:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"])
-    return {k: v / max(len(ids), 1) for k, v in acc.items()}
-
-
-def stats(out, name):
+        per_kernel[short(r["Kernel_Name"])].append(r)
     res = {}
-    for r in rows_of(os.path.join(out, "trace_" + name, "**", "*_kernel_stats.csv")):
-        short = r["Name"].split("(")[0].split("::")[-1]
-        res[short] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
-                      "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
-    # average of the last 20 fused / 200 per-substep dispatches = the timed, resting-contact region
-    tr = [r for r in rows_of(os.path.join(out, "trace_" + name, "**", "*_kernel_trace.csv")) if "k_step" in r["Kernel_Name"]]
-    tail = tr[-(20 if name == "fused" else 200):]
-    if tail:
-        res["k_step_timed_region_avg_ns"] = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail) / len(tail)
-        res["k_step_vgprs"] = int(tail[-1]["VGPR_Count"])
-        res["k_step_workgroup"] = int(tail[-1]["Workgroup_Size_X"])
-        res["k_step_grid"] = int(tail[-1]["Grid_Size_X"])
+    for k, rs in per_kernel.items():
+        ids = sorted(set(int(r["Dispatch_Id"]) for r in rs))[-last:]
+        acc = collections.defaultdict(float)
+        for r in rs:
+            if int(r["Dispatch_Id"]) in ids:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+        res[k] = {c: v / max(len(ids), 1) for c, v in acc.items()}
+        res[k]["dispatches_averaged"] = len(ids)
     return res
 
 
 def bench(out, name):
-    p = os.path.join(out, name)
     try:
-        return json.loads(open(p).read().strip().splitlines()[-1])
+        return json.loads(open(os.path.join(out, name)).read().strip().splitlines()[-1])
     except Exception:
         return None
 
 
+def traffic(out, fetch, write, kernel, last):
+    f = pmc(out, fetch, last).get(kernel, {}).get("FETCH_SIZE")
+    w = pmc(out, write, last).get(kernel, {}).get("WRITE_SIZE")
+    if f is None or w is None:
+        return None
+    return {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "bytes_per_launch": (2.0 * f + w) * 1024.0}
+
+
 def main(out):
-    s = {"bench_fused": bench(out, "bench_fused.json"), "bench_substep": bench(out, "bench_substep.json"),
-         "bench_mixed65536": bench(out, "bench_mixed65536.json"),
-         "kernel_stats_fused": stats(out, "fused"), "kernel_stats_substep": stats(out, "substep")}
-    valu, wave = pmc(out, "valu", 5), pmc(out, "wave", 5)
-    s["pmc_fused_per_launch"] = {**valu, **wave}
-    if valu.get("SQ_ACTIVE_INST_VALU"):
-        s["derived_fused"] = {
-            "valu_insts_per_wave_substep": valu["SQ_INSTS_VALU"] / valu["SQ_WAVES"] / 20.0,
-            "f64_share_of_valu": (valu["SQ_INSTS_VALU_ADD_F64"] + valu["SQ_INSTS_VALU_MUL_F64"] + valu["SQ_INSTS_VALU_FMA_F64"]
-                                  + valu["SQ_INSTS_VALU_TRANS_F64"]) / valu["SQ_INSTS_VALU"],
-            "lane_utilisation": valu["SQ_THREAD_CYCLES_VALU"] / (valu["SQ_ACTIVE_INST_VALU"] * 64.0),
-        }
+    tag = os.path.basename(os.path.normpath(out))
+    s = {"bench": bench(out, "bench.json"), "traces": {}}
+    for d in sorted(glob.glob(os.path.join(out, "trace_*"))):
+        if not os.path.isdir(d):
+            continue
+        name = os.path.basename(d)[len("trace_"):]
+        s["traces"][name] = trace_summary(out, name)
+        src = newest(os.path.join(d, "**", "*_kernel_stats.csv"))
+        if src:
+            shutil.copy(src, os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, name)))
+    valu, wave = pmc(out, "valu", 20).get("k_step<false>", {}), pmc(out, "wave", 20).get("k_step<false>", {})
+    if valu:
+        s["pmc_k_step_fused_per_launch"] = {**valu, **wave}
+        d = {"valu_insts_per_wave_substep": valu["SQ_INSTS_VALU"] / valu["SQ_WAVES"] / 20.0,
+             "f64_share_of_valu": (valu["SQ_INSTS_VALU_ADD_F64"] + valu["SQ_INSTS_VALU_MUL_F64"] + valu["SQ_INSTS_VALU_FMA_F64"]
+                                   + valu["SQ_INSTS_VALU_TRANS_F64"]) / valu["SQ_INSTS_VALU"],
+             "lane_utilisation": valu["SQ_THREAD_CYCLES_VALU"] / (valu["SQ_ACTIVE_INST_VALU"] * 64.0)}
         if wave.get("GRBM_GUI_ACTIVE"):
             cycles = wave["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
-            s["derived_fused"]["kernel_cycles"] = cycles
-            # an f64 VALU wave-instruction occupies its SIMD for 4 cycles (16 lanes/clk); 1024 SIMDs
-            s["derived_fused"]["f64_valu_pipe_busy"] = valu["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cycles
-    traffic = {}
-    for mode in ("fused", "substep"):
-        f = pmc(out, "fetch_" + mode, 5 if mode == "fused" else 100).get("FETCH_SIZE")
-        w = pmc(out, "write_" + mode, 5 if mode == "fused" else 100).get("WRITE_SIZE")
-        if f is not None and w is not None:
-            traffic[mode + "_262144"] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
-                                         "bytes_per_launch": (2.0 * f + w) * 1024.0,
-                                         "algorithmic_bytes_per_launch": 412 * 262144}
-    s["hbm_traffic"] = traffic
+            d["kernel_cycles"] = cycles
+            d["f64_valu_pipe_busy"] = valu["SQ_INSTS_VALU"] / 1024.0 * 4.0 / cycles   # 4 cycles per f64 wave-instruction, 1024 SIMDs
+        s["derived_k_step_fused"] = d
+    t = {}
+    for key, fetch, write, last, n in (("fused_262144", "fetch_fused", "write_fused", 20, 262144),
+                                       ("substep_262144", "fetch_substep", "write_substep", 400, 262144),
+                                       ("substep_2097152", "fetch_substep_big", "write_substep_big", 100, 2097152)):
+        r = traffic(out, fetch, write, "k_step<false>", last)
+        if r:
+            r["algorithmic_bytes_per_launch"] = 412 * n
+            r["source"] = "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of " \
+                          "`bench.py --steps 20 --warmup 5 --only pinned ...`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the " \
+                          "gfx950 correction in MI355X_MICROARCH.md)" % tag
+            t[key] = r
+    s["hbm_traffic"] = t
+    contacts = {}
+    for scene in ("stacks", "mixed_sat"):
+        f, w = pmc(out, "fetch_" + scene, 400), pmc(out, "write_" + scene, 400)
+        for k in f:
+            if "FETCH_SIZE" in f[k] and "WRITE_SIZE" in w.get(k, {}):
+                contacts.setdefault(scene, {})[k] = {"FETCH_SIZE_KiB": f[k]["FETCH_SIZE"], "WRITE_SIZE_KiB": w[k]["WRITE_SIZE"],
+                                                     "bytes_per_launch_uncalibrated": (2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0}
+    if contacts:
+        s["contacts_traffic"] = contacts
     print(json.dumps(s, indent=1))
 
 

@@ -282,8 +282,9 @@ def _frames_api():
     return L
 
 
-def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, narrowphase=0):
-    """One frame of op_contacts_* with joints (numpy records with the layout of `Joint`); narrowphase 1 = GJK + EPA."""
+def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, narrowphase=0, stats=None):
+    """One frame of op_contacts_* with joints (numpy records with the layout of `Joint`); narrowphase 1 = GJK + EPA.
+    stats: optional ContactStats that the substeps add their touching pairs and manifold points to."""
     L = _frames_api()
     b = np.array(bodies, dtype=np.float64).reshape(-1, 38).copy()
     n = b.shape[0]
@@ -295,7 +296,7 @@ def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, nar
     L.op_contacts_set_narrowphase.restype, L.op_contacts_set_narrowphase.argtypes = None, [C.c_void_p, C.c_int]
     L.op_contacts_set_narrowphase(f, narrowphase)
     for _ in range(substeps):
-        L.op_contacts_substep(f, b.ctypes.data, dt / substeps, None, None)
+        L.op_contacts_substep(f, b.ctypes.data, dt / substeps, None, C.byref(stats) if stats is not None else None)
     L.op_contacts_end(f)
     return b
 
