@@ -215,9 +215,9 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
     total = bodies * world_size
     pad = 0.02
     preroll = PREROLL_PILE if layers else PREROLL[scene]
-    if world_size > 1:
+    if world_size > 1 or args.local_shards:
         return run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank,
-                                    local_rank, world_size, steps, warmup)
+                                    local_rank, world_size, steps, warmup, local_shards=args.local_shards)
     count = total
     state, shape_id = contacts_scene(capi, args, kind, total, pitch, layers)
     world = capi.World(device=local_rank, mode=capi.MODE_CONTACTS)
@@ -282,40 +282,77 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
 
 
 def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank, local_rank,
-                         world_size, steps, warmup):
-    """EXTENSION, N > 1: body-body contacts with the world sharded by spatial-hash cell; every rank steps owned + ghost
-    bodies and the boundary bodies are exchanged after EVERY substep with one all-gather (RCCL over xGMI under the
-    nccl backend).  Not in the reference; parity = sharded == single device."""
+                         world_size, steps, warmup, local_shards=0):
+    """EXTENSION, N > 1: body-body contacts through the NATIVE multi-GPU world (xpbd_multi_world_*, csrc/xpbd_multi.cpp):
+    every rank owns a contiguous index range = a slab of space (whole grid rows; for a pile, a pile of its own laid next
+    to its neighbours'), steps owned + ghost bodies, and the boundary bodies travel in one ncclAllGather per substep
+    (RCCL over xGMI); the halo plan is built by the library, a body outrunning halo_margin is an error.  Each rank
+    generates ONLY its own bodies.  local_shards > 0: rehearsal on one GPU -- that many shards in THIS process on device 0
+    with the in-process transport.  Not in the reference; parity = sharded == single device (tests/test_gpu_multi.py)."""
     import torch.distributed as dist
-    from constraint_solver_amd.distributed import GpuBackend, ShardedContactWorld
-    total = bodies * world_size
-    state, shape_id = contacts_scene(capi, args, kind, total, pitch, layers)
-    polys = capi.scene_polytopes(kind)
-    radius = np.array([np.linalg.norm(p["vertices"] - p["centroid"], axis=1).max() for p in polys])
-    centroid = np.array([p["centroid"] for p in polys])
-    backend = GpuBackend(capi, polys, 0.02, device=local_rank)
-    backend.world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT)
-    joints = chain_joints(capi, np, joints_n, total, pitch, capi.default_grid_width(total)) if joints_n else None
-    world = ShardedContactWorld(backend, rank, world_size, state, shape_id, radius, centroid, pad=0.02, halo_margin=0.5,
-                                order=args.order, joints_global=joints)
+    from constraint_solver_amd.sharding import shard_range
+    n_ranks = local_shards or world_size
+    total = bodies * n_ranks
+    parts, sids, first_global = [], [], None
+    my_ranks = range(n_ranks) if local_shards else [rank]
+    for r in my_ranks:
+        first, count = shard_range(total, r, n_ranks)
+        first_global = first if first_global is None else first_global
+        if layers:
+            part, sid = capi.scene_pile(kind, args.seed, total, pitch, layers, first=first, count=count,
+                                        y_offset=r * capi.pile_depth(count, pitch, layers))
+        else:
+            part, sid = capi.scene_generate(kind, args.seed, total, first=first, count=count)
+            if pitch != 2.0:
+                part[:, 31:33] *= pitch / 2.0
+        parts.append(part)
+        sids.append(sid)
+    state, shape_id = np.concatenate(parts), np.concatenate(sids)
+    joints = chain_joints(capi, np, joints_n * n_ranks, total, pitch, capi.default_grid_width(total)) if joints_n else None
+    if local_shards:
+        world = capi.MultiWorld(n_ranks, devices=[local_rank] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=0.5,
+                                narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT, auto_replan=True)
+        transport = "in-process peer copies (rehearsal: %d shards on one device)" % n_ranks
+    else:
+        cid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(cid, src=0)
+        world = capi.MultiWorld(n_ranks, first_rank=rank, devices=[local_rank], transport=capi.TRANSPORT_RCCL, comm_id=cid[0],
+                                halo_margin=0.5, narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT,
+                                auto_replan=True)
+        transport = "ncclAllGather, RCCL bound from %s" % capi.comm_library()
+    world.set_polytopes(capi.scene_polytopes(kind))
+    world.upload(state, shape_id, first_global, total, joints)
     for _ in range(preroll + warmup):
         world.step(FRAME_TIME, args.substeps)
-    wall, _ = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), backend.stream, steps)
+    world.contact_stats()
+    wall, _ = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), torch.cuda.current_stream(), steps)
     result = None
     if rank == 0:
+        halo = world.halo_stats()
+        pairs, touching, points = world.contact_stats()            # of this process's shards (owned + ghost bodies)
+        n_sub = max(steps * args.substeps, 1)
         result = {
             "value": total * args.substeps * steps / wall, "unit": UNIT, "ms_per_step": wall * 1e3 / steps,
             "steps": steps, "warmup": warmup, "preroll_frames": preroll,
             "config": {"workload": contacts_workload(scene, bodies, args.substeps, narrowphase, joints_n, pitch, layers),
                        "bodies_per_gpu": bodies, "bodies_total": total, "substeps": args.substeps, "scene": scene,
-                       "order": args.order,
-                       "sharding": "index ranges of the %s body order + ghost bodies; halo all-gather after every substep (%s)"
-                                   % (args.order, dist.get_backend()),
-                       "halo_bodies_rank0": int(len(world.plan.ghosts[0])), "boundary_capacity": int(world.plan.capacity),
+                       "sharding": "contiguous index ranges = slabs of space, owned + ghost bodies per rank; halo plan, per-frame "
+                                   "halo-validity check and one all-gather per substep inside xpbd_multi_world_step (%s)" % transport,
+                       "halo": halo, "neighbour_pairs_here": pairs, "touching_pairs_per_substep_here": touching / n_sub,
+                       "manifold_points_per_substep_here": points / n_sub,
                        "extension": "not in the reference (parity unpinned; sharded == single device bit for bit)"},
             "roofline": None, "cpu_baseline": None,
         }
-    backend.close()
+        # the same byte model as on one GPU, for THIS rank's shard (owned + ghost bodies are all stepped here)
+        local_bodies = halo["owned"] + halo["ghosts"]
+        substep_bytes = local_bodies * 716 + pairs * 120 + touching / n_sub * 72 + points / n_sub * 144
+        substep_s = wall / n_sub
+        result["roofline"] = {"bound": "hbm", "achieved": substep_bytes / substep_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": substep_bytes / substep_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                              "kernel": "one substep of one rank: integrate + ground, narrowphase, pair solve, halo export / "
+                                        "all-gather / import", "launch_us": substep_s * 1e6, "bytes_per_launch": substep_bytes,
+                              "note": "per-GPU figure from wall time (the exchange is inside it); byte model of DESIGN.md 8"}
+    world.close()
     return result
 
 
@@ -342,8 +379,9 @@ def main():
                     help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (one point per pair)")
     ap.add_argument("--joints", type=int, default=0,
                     help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
-    ap.add_argument("--order", default="spatial", choices=["index", "spatial"],
-                    help="contacts mode, N > 1: shard the caller's index ranges, or renumber bodies by grid cell first")
+    ap.add_argument("--local-shards", type=int, default=0,
+                    help="contacts: rehearsal of the multi-GPU path on ONE GPU -- this many shards in this process on one device, "
+                         "exchanged by the in-process transport (bodies per shard = --bodies)")
     ap.add_argument("--pitch", type=float, default=2.0,
                     help="grid pitch of the scene in metres (generator default 2.0); < 2 packs bodies so that they collide")
     ap.add_argument("--layers", type=int, default=0,

@@ -16,9 +16,9 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 ORACLE = os.path.join(ROOT, "oracle")
 
-HIP_SOURCES = ["xpbd_kernels.hip", "xpbd_pairs.hip", "xpbd_contacts.hip", "xpbd_gjk.hip", "xpbd_world.cpp"]
+HIP_SOURCES = ["xpbd_kernels.hip", "xpbd_pairs.hip", "xpbd_contacts.hip", "xpbd_gjk.hip", "xpbd_world.cpp", "xpbd_multi.cpp", "xpbd_rccl.cpp"]
 # -ffp-contract=off is a correctness flag: the reference (Rust) never fuses a*b+c.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-ldl"]
 CXX_FLAGS = ["-O2", "-ffp-contract=off", "-std=c++17", "-Wall", "-Wextra"]
 
 

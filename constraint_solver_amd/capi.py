@@ -20,7 +20,7 @@ MODE_PER_SUBSTEP = 1
 MODE_CONTACTS = 2  # extension: ground + body-body contacts
 FLAG_TRACE_CONTACTS = 1
 
-OK, E_INVALID, E_HIP, E_OOM, E_SINGULAR_INERTIA, E_NO_DEVICE, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+OK, E_INVALID, E_HIP, E_OOM, E_SINGULAR_INERTIA, E_NO_DEVICE, E_CAPACITY, E_HALO = 0, -1, -2, -3, -4, -5, -6, -7
 
 # xpbd_rigid field -> (first double, count); order of reference src/rigid.rs:6-50
 RIGID_FIELDS = {
@@ -41,7 +41,11 @@ ABI_SYMBOLS = [
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_import_dynamic_rows", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
     "xpbd_world_set_sat_schedule",
-    "xpbd_selftest_hbm_copy",
+    "xpbd_selftest_hbm_copy", "xpbd_world_snapshot_positions", "xpbd_world_max_displacement2",
+    "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
+    "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
+    "xpbd_multi_world_synchronize", "xpbd_multi_world_download", "xpbd_multi_world_halo_stats", "xpbd_multi_world_contact_stats",
+    "xpbd_halo_cell_key", "xpbd_halo_plan",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
 
@@ -59,6 +63,18 @@ class Config(C.Structure):
 
 _u32p = C.POINTER(C.c_uint32)
 _f64p = C.POINTER(C.c_double)
+
+
+class MultiConfig(C.Structure):
+    """xpbd_multi_config"""
+    _fields_ = [("struct_size", C.c_uint32), ("n_ranks", C.c_uint32), ("first_rank", C.c_uint32), ("n_local", C.c_uint32),
+                ("devices", C.POINTER(C.c_int32)), ("transport", C.c_uint32), ("flags", C.c_uint32), ("comm_id", C.c_char_p),
+                ("contact_pad", C.c_double), ("halo_margin", C.c_double), ("narrowphase", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+COMM_ID_BYTES = 128
+TRANSPORT_RCCL, TRANSPORT_LOCAL = 0, 1
+MULTI_AUTO_REPLAN = 1
 
 
 class PolytopeDesc(C.Structure):
@@ -124,6 +140,26 @@ def hip_lib():
         L.xpbd_step_one.argtypes = [C.c_void_p, _f64p, C.c_uint32, C.c_double, C.c_uint32]
         L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
         L.xpbd_selftest_hbm_copy.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, _f64p]
+        L.xpbd_world_snapshot_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_max_displacement2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.xpbd_comm_unique_id.argtypes = [C.c_char_p]
+        L.xpbd_multi_config_default.argtypes = [C.POINTER(MultiConfig)]
+        L.xpbd_multi_config_default.restype = None
+        L.xpbd_multi_world_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(MultiConfig)]
+        L.xpbd_multi_world_destroy.argtypes = [C.c_void_p]
+        L.xpbd_multi_world_destroy.restype = None
+        L.xpbd_multi_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
+        L.xpbd_multi_world_upload.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.xpbd_multi_world_step.argtypes = [C.c_void_p, C.c_double, C.c_uint32]
+        L.xpbd_multi_world_replan.argtypes = [C.c_void_p]
+        L.xpbd_multi_world_synchronize.argtypes = [C.c_void_p]
+        L.xpbd_multi_world_download.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.xpbd_multi_world_halo_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), _f64p]
+        L.xpbd_multi_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.xpbd_halo_cell_key.argtypes = [_f64p, C.c_double]
+        L.xpbd_halo_cell_key.restype = C.c_int64
+        L.xpbd_halo_plan.argtypes = [C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p,
+                                     _u32p, C.c_uint32]
         L.xpbd_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
         L.xpbd_world_narrowphase.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         L.xpbd_world_narrowphase_gjk.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
@@ -257,16 +293,7 @@ class World:
 
     def set_polytopes(self, polytopes):
         """polytopes: list of dicts with vertices (V,3), edges (E,2), face_offsets (F+1), face_indices, centroid (3)."""
-        keep, descs = [], (PolytopeDesc * len(polytopes))()
-        for d, p in zip(descs, polytopes):
-            v = np.ascontiguousarray(p["vertices"], dtype=np.float64).reshape(-1, 3)
-            e = np.ascontiguousarray(p["edges"], dtype=np.uint32).reshape(-1, 2)
-            fo = np.ascontiguousarray(p["face_offsets"], dtype=np.uint32)
-            fi = np.ascontiguousarray(p["face_indices"], dtype=np.uint32)
-            keep += [v, e, fo, fi]
-            d.vertices_xyz, d.edges, d.face_offsets, d.face_indices = _f64(v), _u32(e), _u32(fo), _u32(fi)
-            d.n_vertices, d.n_edges, d.n_faces = v.shape[0], e.shape[0], fo.size - 1
-            d.centroid[:] = [float(x) for x in p["centroid"]]
+        descs, _keep = polytope_descs(polytopes)
         _check(hip_lib().xpbd_world_set_polytopes(self._h, descs, len(polytopes)))
 
     def narrowphase(self, pairs):
@@ -353,6 +380,132 @@ class World:
         _check(hip_lib().xpbd_world_set_mode(self._h, mode))
 
 
+def polytope_descs(polytopes):
+    """(xpbd_polytope array, the numpy arrays it points into) from a list of polytope dicts."""
+    keep, descs = [], (PolytopeDesc * len(polytopes))()
+    for d, p in zip(descs, polytopes):
+        v = np.ascontiguousarray(p["vertices"], dtype=np.float64).reshape(-1, 3)
+        e = np.ascontiguousarray(p["edges"], dtype=np.uint32).reshape(-1, 2)
+        fo = np.ascontiguousarray(p["face_offsets"], dtype=np.uint32)
+        fi = np.ascontiguousarray(p["face_indices"], dtype=np.uint32)
+        keep += [v, e, fo, fi]
+        d.vertices_xyz, d.edges, d.face_offsets, d.face_indices = _f64(v), _u32(e), _u32(fo), _u32(fi)
+        d.n_vertices, d.n_edges, d.n_faces = v.shape[0], e.shape[0], fo.size - 1
+        d.centroid[:] = [float(x) for x in p["centroid"]]
+    return descs, keep
+
+
+def pile_depth(count, pitch, layers):
+    """Extent in y (metres, one pitch of clearance included) of a scene_pile of `count` bodies: piles laid side by side at
+    this spacing form one continuous pile."""
+    per_layer = (count + layers - 1) // layers
+    w = default_grid_width(per_layer)
+    return pitch * ((per_layer + w - 1) // w)
+
+
+def comm_library():
+    """Path of the RCCL library the multi-GPU world is bound to (None if none could be loaded)."""
+    L = hip_lib()
+    L.xpbd_comm_library.restype = C.c_char_p
+    p = L.xpbd_comm_library()
+    return p.decode() if p else None
+
+
+def comm_unique_id():
+    """XPBD_COMM_ID_BYTES of a fresh RCCL communicator id (made on one rank, handed to all)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(hip_lib().xpbd_comm_unique_id(buf))
+    return buf.raw
+
+
+class MultiWorld:
+    """xpbd_multi_world: this process's local shards of an N-body world with body-body contacts sharded over n_ranks GPUs
+    (EXTENSION; the caller is World::integrate, src/world.rs:34-43)."""
+
+    def __init__(self, n_ranks, first_rank=0, devices=(0,), transport=TRANSPORT_RCCL, comm_id=None, pad=0.02, halo_margin=0.5,
+                 narrowphase=NARROWPHASE_SAT, auto_replan=False):
+        L = hip_lib()
+        cfg = MultiConfig()
+        L.xpbd_multi_config_default(C.byref(cfg))
+        self._devices = (C.c_int32 * len(devices))(*devices)
+        self._comm_id = comm_id
+        cfg.n_ranks, cfg.first_rank, cfg.n_local, cfg.devices = n_ranks, first_rank, len(devices), self._devices
+        cfg.transport, cfg.flags, cfg.comm_id = transport, MULTI_AUTO_REPLAN if auto_replan else 0, comm_id
+        cfg.contact_pad, cfg.halo_margin, cfg.narrowphase = pad, halo_margin, narrowphase
+        self._h = C.c_void_p()
+        _check(L.xpbd_multi_world_create(C.byref(self._h), C.byref(cfg)))
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            hip_lib().xpbd_multi_world_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_polytopes(self, polytopes):
+        descs, _keep = polytope_descs(polytopes)
+        _check(hip_lib().xpbd_multi_world_set_polytopes(self._h, descs, len(polytopes)))
+
+    def upload(self, bodies, shape_id, first_global, n_global, joints=None):
+        """bodies / shape_id: the bodies this process's shards own, global indices [first_global, first_global + len)."""
+        b = np.ascontiguousarray(bodies, dtype=np.float64).reshape(-1, RIGID_DOUBLES)
+        sid = None if shape_id is None else np.ascontiguousarray(shape_id, dtype=np.uint32)
+        j = np.zeros(0, dtype=JOINT_DTYPE) if joints is None else np.ascontiguousarray(joints, dtype=JOINT_DTYPE)
+        _check(hip_lib().xpbd_multi_world_upload(self._h, b.ctypes.data, None if sid is None else _u32(sid), first_global, b.shape[0],
+                                                 n_global, j.ctypes.data if j.size else None, j.size))
+        self.n = b.shape[0]
+
+    def step(self, dt, substeps):
+        _check(hip_lib().xpbd_multi_world_step(self._h, dt, substeps))
+
+    def replan(self):
+        _check(hip_lib().xpbd_multi_world_replan(self._h))
+
+    def synchronize(self):
+        _check(hip_lib().xpbd_multi_world_synchronize(self._h))
+
+    def download(self):
+        out = np.empty((self.n, RIGID_DOUBLES), dtype=np.float64)
+        _check(hip_lib().xpbd_multi_world_download(self._h, out.ctypes.data, self.n))
+        return out
+
+    def halo_stats(self):
+        """dict: bodies of the world, owned / ghost / boundary bodies here, rows per rank of the all-gather, plans made, and
+        the largest distance a body had travelled at the last check."""
+        out, moved = (C.c_uint64 * 6)(), C.c_double(0.0)
+        _check(hip_lib().xpbd_multi_world_halo_stats(self._h, out, C.byref(moved)))
+        keys = ("bodies_global", "owned", "ghosts", "boundary", "rows_per_rank", "plans")
+        return dict(zip(keys, (int(x) for x in out)), max_displacement=moved.value)
+
+    def contact_stats(self):
+        out = (C.c_uint64 * 3)()
+        _check(hip_lib().xpbd_multi_world_contact_stats(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+
+def halo_cell_key(centre, edge):
+    c = np.ascontiguousarray(centre, dtype=np.float64)
+    return int(hip_lib().xpbd_halo_cell_key(_f64(c), edge))
+
+
+def halo_plan(cell_keys, n_ranks, rank, joints=None):
+    """(ghost ids, boundary ids) of one rank from the grid-cell keys of ALL bodies: host-only, as xpbd_multi_world_upload plans."""
+    keys = np.ascontiguousarray(cell_keys, dtype=np.int64)
+    j = np.zeros(0, dtype=JOINT_DTYPE) if joints is None else np.ascontiguousarray(joints, dtype=JOINT_DTYPE)
+    ghosts, boundary = np.zeros(len(keys), dtype=np.uint32), np.zeros(len(keys), dtype=np.uint32)
+    ng, nb = C.c_uint32(0), C.c_uint32(0)
+    _check(hip_lib().xpbd_halo_plan(keys.ctypes.data_as(C.POINTER(C.c_int64)), len(keys), n_ranks, rank, j.ctypes.data if j.size else None,
+                                    j.size, _u32(ghosts), C.byref(ng), _u32(boundary), C.byref(nb), len(keys)))
+    return ghosts[: ng.value].copy(), boundary[: nb.value].copy()
+
+
 def step_one(rigid, verts_xyz, dt, substeps):
     """solver::step for one body (src/solver.rs:3) through xpbd_step_one; returns the new 38-double state."""
     r = np.array(rigid, dtype=np.float64).reshape(RIGID_DOUBLES).copy()
@@ -409,7 +562,7 @@ def scene_generate(kind, seed, n, first=0, count=None, grid_w=None):
     return bodies, sid
 
 
-def scene_pile(kind, seed, n, pitch, layers, layer_gap=2.5, lift=0.6):
+def scene_pile(kind, seed, n, pitch, layers, layer_gap=2.5, lift=0.6, first=0, count=None, y_offset=0.0):
     """The seeded scene re-gridded into a PILE for the body-body contact extension: `layers` layers of a square grid at
     `pitch` metres, `layer_gap` metres apart, the CENTRES OF MASS on the grid points (world centre = position +
     center_of_mass whatever the rotation, src/rigid.rs:75-80; the shapes' origins are a corner for the cube and the
@@ -419,13 +572,14 @@ def scene_pile(kind, seed, n, pitch, layers, layer_gap=2.5, lift=0.6):
     mod 3) and pitch >= 1.4 keeps a cube clear of the smaller shapes; boxes need pitch >= 1.75.  A scene with deep
     initial overlaps is resolved in ONE substep (XPBD has no velocity clamp), i.e. depth / h = 120 m/s for 0.1 m, and
     never reaches a steady contact regime."""
-    bodies, sid = scene_generate(kind, seed, n)
-    per_layer = (n + layers - 1) // layers
+    count = n - first if count is None else count     # bodies [first, first + count) of the n-body seeded scene form the pile
+    bodies, sid = scene_generate(kind, seed, n, first=first, count=count)
+    per_layer = (count + layers - 1) // layers
     w = default_grid_width(per_layer)
-    i = np.arange(n)
+    i = np.arange(count)
     k = i % per_layer
     bodies[:, 31] = pitch * (k % w) - bodies[:, 28]
-    bodies[:, 32] = pitch * (k // w) - bodies[:, 29]
+    bodies[:, 32] = y_offset + pitch * (k // w) - bodies[:, 29]
     bodies[:, 33] += lift + layer_gap * (i // per_layer) + (0.5 - bodies[:, 30])
     return bodies, sid
 

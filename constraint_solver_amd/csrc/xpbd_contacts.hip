@@ -851,6 +851,47 @@ __global__ void k_import_dynamic(BodyArrays b, const uint32_t *__restrict__ indi
     b.dyn[(size_t)f * b.stride + indices[k]] = buf[(size_t)(rows ? rows[k] : k) * kDynFields + f];
 }
 
+// Halo validity (multi-GPU): positions of the listed bodies when the halos were chosen ...
+__global__ void k_snapshot_positions(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n, double *__restrict__ snapshot)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    const Vec3 p = load3(b.dyn, D_POS, b.stride, indices[k]);
+    snapshot[3 * (size_t)k + 0] = p.x, snapshot[3 * (size_t)k + 1] = p.y, snapshot[3 * (size_t)k + 2] = p.z;
+}
+
+// ... and the largest squared distance any of them has travelled since: *out = max(*out, max_k |pos_k - snapshot_k|^2).
+// Non-negative doubles order like their bit patterns, so the maximum is an integer atomicMax (one per workgroup); a NaN
+// position counts as +inf.
+__global__ void __launch_bounds__(kBlock) k_max_displacement2(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n,
+                                                              const double *__restrict__ snapshot, double *__restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    double d2 = 0.0;
+    if (k < n) {
+        const Vec3 p = load3(b.dyn, D_POS, b.stride, indices[k]);
+        const Vec3 d = p - Vec3{snapshot[3 * (size_t)k + 0], snapshot[3 * (size_t)k + 1], snapshot[3 * (size_t)k + 2]};
+        d2 = dot(d, d);
+        if (!(d2 <= DBL_MAX))
+            d2 = __longlong_as_double(0x7FF0000000000000ll);
+    }
+    for (uint32_t off = 32; off; off >>= 1) {
+        const double o = __shfl_xor(d2, off, 64);
+        d2 = o > d2 ? o : d2;
+    }
+    __shared__ double part[kBlock / 64];
+    if ((threadIdx.x & 63u) == 0)
+        part[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < kBlock / 64; ++w)
+            d2 = part[w] > d2 ? part[w] : d2;
+        if (d2 > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(d2));
+    }
+}
+
 uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 } // namespace
@@ -996,6 +1037,21 @@ hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, c
 {
     if (n)
         hipLaunchKernelGGL(k_import_dynamic, dim3(blocks_for(n * kDynFields)), dim3(kBlock), 0, stream, b, indices, rows, n, buf);
+    return hipGetLastError();
+}
+
+hipError_t launch_snapshot_positions(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *snapshot, hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_snapshot_positions, dim3(blocks_for(n)), dim3(kBlock), 0, stream, b, indices, n, snapshot);
+    return hipGetLastError();
+}
+
+hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *snapshot, double *out,
+                                    hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_max_displacement2, dim3(blocks_for(n)), dim3(kBlock), 0, stream, b, indices, n, snapshot, out);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "xpbd_internal.h"
 #include "xpbd_kernels.h"
 #include "xpbd_math.hpp"
 #include "xpbd_contacts.h"
@@ -45,6 +46,23 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 uint32_t round_up(uint32_t v, uint32_t to) { return (v + to - 1) / to * to; }
+
+} // namespace
+
+namespace xpbd {
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+} // namespace xpbd
+
+namespace {
 
 // A device allocation that only ever grows.
 struct DeviceBuffer {
@@ -998,6 +1016,26 @@ int xpbd_world_import_dynamic_rows(xpbd_world *w, const uint32_t *dev_indices, c
     if (int rc = bind_device(w))
         return rc;
     XPBD_HIP_TRY(xpbd::launch_import_dynamic(w->arrays(), dev_indices, dev_rows, n, dev_buf, w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_snapshot_positions(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_snapshot)
+{
+    if (!w || (n && (!dev_indices || !dev_snapshot)))
+        return fail(XPBD_E_INVALID, "xpbd_world_snapshot_positions: NULL argument");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_snapshot_positions(w->arrays(), dev_indices, n, dev_snapshot, w->stream));
+    return XPBD_OK;
+}
+
+int xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_snapshot, double *dev_max)
+{
+    if (!w || !dev_max || (n && (!dev_indices || !dev_snapshot)))
+        return fail(XPBD_E_INVALID, "xpbd_world_max_displacement2: NULL argument");
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(xpbd::launch_max_displacement2(w->arrays(), dev_indices, n, dev_snapshot, dev_max, w->stream));
     return XPBD_OK;
 }
 

@@ -111,6 +111,34 @@ pub struct XpbdWorld {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+pub struct XpbdMultiWorld {
+    _private: [u8; 0],
+}
+
+pub const XPBD_COMM_ID_BYTES: usize = 128;
+pub const XPBD_TRANSPORT_RCCL: u32 = 0;
+pub const XPBD_TRANSPORT_LOCAL: u32 = 1;
+pub const XPBD_MULTI_AUTO_REPLAN: u32 = 1;
+pub const XPBD_E_HALO: c_int = -7;
+
+/// xpbd_multi_config (include/xpbd.h)
+#[repr(C)]
+pub struct XpbdMultiConfig {
+    pub struct_size: u32,
+    pub n_ranks: u32,
+    pub first_rank: u32,
+    pub n_local: u32,
+    pub devices: *const i32,
+    pub transport: u32,
+    pub flags: u32,
+    pub comm_id: *const u8,
+    pub contact_pad: f64,
+    pub halo_margin: f64,
+    pub narrowphase: u32,
+    pub reserved: u32,
+}
+
 #[link(name = "xpbd_hip")]
 extern "C" {
     pub fn xpbd_abi_version() -> u32;
@@ -145,6 +173,26 @@ extern "C" {
     pub fn xpbd_world_build_neighbours(w: *mut XpbdWorld, dt: f64, n_entries_out: *mut u32) -> c_int;
     pub fn xpbd_world_download_neighbours(w: *mut XpbdWorld, offsets: *mut u32, neighbours: *mut u32, cap: u32) -> c_int;
     pub fn xpbd_world_set_joints(w: *mut XpbdWorld, joints: *const XpbdJoint, n_joints: u32) -> c_int;
+    pub fn xpbd_world_snapshot_positions(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *mut f64) -> c_int;
+    pub fn xpbd_world_max_displacement2(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *const f64, dev_max: *mut f64) -> c_int;
+    // ---- extension: the multi-GPU world (one call per frame; the library owns streams, RCCL communicators and the halo plan) ----
+    pub fn xpbd_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn xpbd_comm_library() -> *const c_char;
+    pub fn xpbd_multi_config_default(cfg: *mut XpbdMultiConfig);
+    pub fn xpbd_multi_world_create(out: *mut *mut XpbdMultiWorld, cfg: *const XpbdMultiConfig) -> c_int;
+    pub fn xpbd_multi_world_destroy(mw: *mut XpbdMultiWorld);
+    pub fn xpbd_multi_world_set_polytopes(mw: *mut XpbdMultiWorld, shapes: *const XpbdPolytope, n_shapes: u32) -> c_int;
+    pub fn xpbd_multi_world_upload(mw: *mut XpbdMultiWorld, bodies: *const XpbdRigid, shape_id: *const u32, first_global: u32, n_bodies: u32,
+                                   n_global: u32, joints: *const XpbdJoint, n_joints: u32) -> c_int;
+    pub fn xpbd_multi_world_step(mw: *mut XpbdMultiWorld, dt: f64, substeps: u32) -> c_int;
+    pub fn xpbd_multi_world_replan(mw: *mut XpbdMultiWorld) -> c_int;
+    pub fn xpbd_multi_world_synchronize(mw: *mut XpbdMultiWorld) -> c_int;
+    pub fn xpbd_multi_world_download(mw: *mut XpbdMultiWorld, out: *mut XpbdRigid, n: u32) -> c_int;
+    pub fn xpbd_multi_world_halo_stats(mw: *mut XpbdMultiWorld, out: *mut u64, max_displacement: *mut f64) -> c_int;
+    pub fn xpbd_multi_world_contact_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int;
+    pub fn xpbd_halo_cell_key(centre: *const f64, cell_edge: f64) -> i64;
+    pub fn xpbd_halo_plan(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint, n_joints: u32,
+                          ghosts: *mut u32, n_ghosts: *mut u32, boundary: *mut u32, n_boundary: *mut u32, cap: u32) -> c_int;
     pub fn xpbd_world_contacts_begin(w: *mut XpbdWorld, dt: f64) -> c_int;
     pub fn xpbd_world_contacts_substep(w: *mut XpbdWorld, h: f64) -> c_int;
     pub fn xpbd_world_export_dynamic(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_buf: *mut f64) -> c_int;

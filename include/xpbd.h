@@ -45,6 +45,7 @@ extern "C" {
 #define XPBD_E_SINGULAR_INERTIA (-4)  /* mirrors the panic at src/rigid.rs:59 */
 #define XPBD_E_NO_DEVICE        (-5)  /* no usable gfx950 device */
 #define XPBD_E_CAPACITY         (-6)  /* caller buffer too small */
+#define XPBD_E_HALO              (-7)  /* multi-GPU: a body outran halo_margin since the halos were planned */
 
 /* A shape may have at most this many vertices (contact set is a u32 mask). */
 #define XPBD_MAX_SHAPE_VERTS 32u
@@ -271,6 +272,77 @@ int  xpbd_world_import_dynamic(xpbd_world *w, const uint32_t *dev_indices, uint3
  * rank's boundary bodies back to back) is imported as it is, without a gather pass of the host framework. */
 int  xpbd_world_import_dynamic_rows(xpbd_world *w, const uint32_t *dev_indices, const uint32_t *dev_rows, uint32_t n,
                                     const double *dev_buf);
+
+/* Halo validity for hosts that run their own exchange loop: dev_snapshot[3k..3k+2] = position of body dev_indices[k] (at
+ * plan time), and later *dev_max = max(*dev_max, max_k |position_k - snapshot_k|^2) -- the largest squared distance any
+ * listed body has travelled (a NaN position counts as +inf).  Device pointers; asynchronous on the world's stream. */
+int  xpbd_world_snapshot_positions(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_snapshot);
+int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_snapshot, double *dev_max);
+
+/* ---------------------------------------------------------------------------
+ * Multi-GPU world (EXTENSION): the caller is still World::integrate (src/world.rs:34-43), now over an N-body
+ * world in XPBD_MODE_CONTACTS whose bodies are sharded over the GPUs of one node by contiguous global index range -- order
+ * the bodies so that index ranges are compact in space (grid rows, spatial-hash cell order) and the halos are thin.
+ * One xpbd_multi_world drives this process's LOCAL shards of the n_ranks shards of the world: all of them (one process owns
+ * every GPU) or one each (one process per GPU).  Every shard steps its owned bodies plus ghost copies of the remote
+ * bodies within reach, and after EVERY substep the boundary bodies' 13 dynamic doubles travel in ONE all-gather (RCCL over
+ * xGMI; XPBD_TRANSPORT_LOCAL = peer copies inside one process, also the single-GPU rehearsal with several shards on one
+ * device).  The library builds the halo plan itself (no rank holds the global scene) and checks once per frame, over all
+ * ranks, how far any body has travelled since: beyond halo_margin the step FAILS with XPBD_E_HALO rather than lose remote
+ * contacts silently; XPBD_MULTI_AUTO_REPLAN re-plans at half the margin.  Result: bit-identical to one xpbd_world over
+ * the same bodies in the same order.
+ * ------------------------------------------------------------------------- */
+#define XPBD_COMM_ID_BYTES 128u         /* sizeof(ncclUniqueId) */
+#define XPBD_TRANSPORT_RCCL  0u
+#define XPBD_TRANSPORT_LOCAL 1u         /* needs n_local == n_ranks */
+#define XPBD_MULTI_AUTO_REPLAN 1u
+
+typedef struct xpbd_multi_config {
+    uint32_t struct_size;   /* = sizeof(xpbd_multi_config) */
+    uint32_t n_ranks;       /* shards of the whole world (<= 64) */
+    uint32_t first_rank;    /* global rank of this process's first shard */
+    uint32_t n_local;       /* shards driven by this process: ranks [first_rank, first_rank + n_local) */
+    const int32_t *devices; /* n_local HIP device ordinals */
+    uint32_t transport;     /* XPBD_TRANSPORT_* */
+    uint32_t flags;         /* XPBD_MULTI_* */
+    const uint8_t *comm_id; /* RCCL: XPBD_COMM_ID_BYTES from xpbd_comm_unique_id, the same on every rank */
+    double   contact_pad;   /* as xpbd_world_set_contact_pad (default 0.02) */
+    double   halo_margin;   /* how far a body may travel between plans (default 0.5 m) */
+    uint32_t narrowphase;   /* XPBD_NARROWPHASE_* */
+    uint32_t reserved;      /* must be 0 */
+} xpbd_multi_config;
+
+typedef struct xpbd_multi_world xpbd_multi_world;
+
+/* One rank creates the communicator id; the host hands it to every rank (any channel) before xpbd_multi_world_create. */
+int  xpbd_comm_unique_id(uint8_t id[XPBD_COMM_ID_BYTES]);
+/* The RCCL library the collectives are bound to at run time (a copy already loaded into the process is preferred over
+ * loading a second one), or NULL if none could be loaded. */
+const char *xpbd_comm_library(void);
+void xpbd_multi_config_default(xpbd_multi_config *cfg);
+int  xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg);   /* collective over all ranks (RCCL) */
+void xpbd_multi_world_destroy(xpbd_multi_world *mw);
+int  xpbd_multi_world_set_polytopes(xpbd_multi_world *mw, const xpbd_polytope *shapes, uint32_t n_shapes);
+/* bodies: the bodies this process's shards own = global indices [first_global, first_global + n_bodies) of n_global (rank r
+ * owns the r-th of n_ranks near-equal contiguous ranges, the first n_global % n_ranks one body longer); joints: ALL joints of
+ * the world with GLOBAL body indices, the same list on every rank.  Collective: builds the halo plan. */
+int  xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, const uint32_t *shape_id, uint32_t first_global,
+                             uint32_t n_bodies, uint32_t n_global, const xpbd_joint *joints, uint32_t n_joints);
+/* xpbd_world_step(dt, substeps) of the whole sharded world; collective, asynchronous after the broadphase. */
+int  xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps);
+int  xpbd_multi_world_replan(xpbd_multi_world *mw);                                     /* collective; clears XPBD_E_HALO */
+int  xpbd_multi_world_synchronize(xpbd_multi_world *mw);
+int  xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n);     /* the owned bodies, global order */
+/* out = {bodies of the world, owned here, ghosts here, boundary bodies here, rows per rank of the all-gather, plans made};
+ * *max_displacement (optional) = the largest distance any body had travelled at the last check (metres). */
+int  xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *max_displacement);
+int  xpbd_multi_world_contact_stats(xpbd_multi_world *mw, uint64_t out[3]);             /* sums of xpbd_world_contact_stats */
+/* Diagnostics, host only (no device needed): the grid cell key of a bounding-sphere centre, and one rank's halo plan from
+ * the cell keys of all bodies (ascending ghost ids: the remote bodies it mirrors; ascending boundary ids: its own bodies
+ * that others mirror) exactly as xpbd_multi_world_upload computes it. */
+int64_t xpbd_halo_cell_key(const double centre[3], double cell_edge);
+int  xpbd_halo_plan(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, const xpbd_joint *joints,
+                    uint32_t n_joints, uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary, uint32_t *n_boundary, uint32_t cap);
 
 /* State history: the device-side counterpart of the reference app's `states: Vec<(World,
  * DebugLines)>` with its `current_state` cursor (src/app.rs:48, 206-212), which lets the user

@@ -1,0 +1,54 @@
+"""The native halo planner (csrc/xpbd_multi.cpp, host-only part behind xpbd_halo_plan) against the Python planner of
+constraint_solver_amd/distributed.py, which the gloo tests pin to "sharded == single device": same ghosts, same boundary
+bodies, for random clouds, piles, and joints that cross shard boundaries.  No GPU needed."""
+import numpy as np
+import pytest
+
+from constraint_solver_amd import capi
+from constraint_solver_amd.distributed import HaloPlan, bounding_spheres
+
+
+def keys_of(centre, radius, pad, margin):
+    edge = 2.0 * (float(radius.max()) + pad + margin)
+    return np.array([capi.halo_cell_key(c, edge) for c in centre], dtype=np.int64)
+
+
+@pytest.mark.parametrize("world_size", [2, 3, 5])
+@pytest.mark.parametrize("case", ["line", "cloud", "pile", "joints"])
+def test_native_plan_equals_python_plan(case, world_size):
+    rng = np.random.default_rng(7)
+    n = 997
+    polys = capi.scene_polytopes(capi.SCENE_MIXED_DROP)
+    radius = np.array([np.linalg.norm(p["vertices"] - p["centroid"], axis=1).max() for p in polys])
+    centroid = np.array([p["centroid"] for p in polys])
+    if case == "pile":
+        bodies, sid = capi.scene_pile(capi.SCENE_MIXED_DROP, 3, n, 1.4, 3)
+    else:
+        bodies, sid = capi.scene_generate(capi.SCENE_MIXED_DROP, 3, n)
+        if case == "cloud":
+            bodies[:, 31:34] = rng.uniform(-6, 6, (n, 3))
+    joints = None
+    if case == "joints":
+        a = rng.choice(n - 200, 40, replace=False)
+        joints = np.zeros(40, dtype=capi.JOINT_DTYPE)
+        joints["body_a"], joints["body_b"] = a, a + rng.integers(1, 200, 40)      # many cross shard boundaries, far apart
+    centre, rad = bounding_spheres(bodies, sid, radius, centroid)
+    pad, margin = 0.02, 0.75
+    pairs = None if joints is None else np.stack([joints["body_a"], joints["body_b"]], axis=1).astype(np.int64)
+    plan = HaloPlan(centre, rad, world_size, margin, pad, joint_pairs=pairs)
+    keys = keys_of(centre, rad, pad, margin)
+    total_ghosts = 0
+    for rank in range(world_size):
+        ghosts, boundary = capi.halo_plan(keys, world_size, rank, joints)
+        assert np.array_equal(ghosts, np.sort(plan.ghosts[rank]))
+        assert np.array_equal(boundary, plan.boundary[rank])
+        total_ghosts += len(ghosts)
+    assert total_ghosts > 0
+
+
+def test_far_and_nan_centres_are_clamped_not_dropped():
+    centre = np.array([[0.0, 0.0, 0.0], [1e30, 0.0, 0.0], [np.nan, 1.0, 1.0], [-1e30, -1e30, 5.0], [0.5, 0.5, 0.5]])
+    keys = np.array([capi.halo_cell_key(c, 2.0) for c in centre], dtype=np.int64)
+    assert keys[0] == keys[4] and len(set(keys.tolist())) == 4
+    ghosts, boundary = capi.halo_plan(keys, 2, 0)                   # rank 0 owns bodies 0..2, rank 1 bodies 3, 4
+    assert ghosts.tolist() == [4] and boundary.tolist() == [0]      # body 4 shares body 0's cell; the far ones reach nobody
