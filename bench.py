@@ -373,6 +373,8 @@ def main():
                     help="skip the informational extra measurements (unfused roofline, HBM-resident size, PCIe-inclusive)")
     ap.add_argument("--no-contacts", action="store_true",
                     help="skip the `contacts` sub-results of the default run (box stacks with SAT contacts, mixed polyhedra on GJK/EPA)")
+    ap.add_argument("--contacts-timeout", type=int, default=420,
+                    help="N > 1: seconds after which the contacts sub-results are abandoned and the line is printed without them")
     ap.add_argument("--only", default="", help="profiling aid: run ONLY this part ('pinned', or a contacts sub-result name) "
                                                "with no extras and no CPU leg")
     ap.add_argument("--narrowphase", default="sat", choices=["sat", "gjk"],
@@ -608,11 +610,30 @@ def main():
     # ---------------------------------------------------------------- the north-star workloads (extension)
     if not args.no_contacts and not args.only and mode == capi.MODE_FUSED:
         subs = {}
+        if world_size > 1:
+            # The sub-results run collectives of their own (the native multi-GPU world).  Should one of them hang -- a rank
+            # lost, a communicator that never forms -- the headline line must still come out: after this many seconds rank 0
+            # prints what it has and every rank leaves.
+            import signal
+
+            def give_up(signum, frame):
+                if rank == 0:
+                    subs["error"] = "timed out after %d s" % args.contacts_timeout
+                    result["contacts"] = subs
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+            signal.signal(signal.SIGALRM, give_up)
+            signal.alarm(args.contacts_timeout)
         for name, cfg in sub_runs.items():
-            r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
-                             steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, **cfg)
+            try:
+                r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
+                                 steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, **cfg)
+            except capi.XpbdError as e:                     # e.g. XPBD_E_HALO in a scene that outruns its margin
+                r = {"error": str(e)}
             if rank == 0:
                 subs[name] = r
+        if world_size > 1:
+            signal.alarm(0)
         if rank == 0:
             result["contacts"] = subs
     if rank == 0:

@@ -148,3 +148,49 @@ def test_multi_world_argument_errors():
             mw.step(DT, 0)
         mw.step(DT, 4)
         assert mw.download().shape == (10, 38)
+
+
+def test_rccl_world_beside_torch_distributed_nccl(tmp_path):
+    """bench.py --gpus N runs the native world inside a process that has torch.distributed's nccl (= RCCL) group up and
+    hands the communicator id around with broadcast_object_list.  The same here with a one-rank group (one GPU), in a
+    child process: the library must bind to the RCCL copy the process already carries and work beside it."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json
+sys.path[:0] = [%r, %r]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from constraint_solver_amd import capi
+from halo_common import line_scene
+cid = [capi.comm_unique_id()]
+dist.broadcast_object_list(cid, src=0)
+bodies, sid = line_scene(capi, capi.SCENE_BOXES_DROP, 64, 2, 1.3)
+with capi.MultiWorld(1, devices=[0], transport=capi.TRANSPORT_RCCL, comm_id=cid[0]) as mw:
+    mw.set_polytopes(capi.scene_polytopes(capi.SCENE_BOXES_DROP))
+    mw.upload(bodies, sid, 0, 64)
+    for _ in range(5):
+        mw.step(1 / 60, 4)
+    got = mw.download()
+t = torch.ones(4, device="cuda")
+dist.all_reduce(t)
+with capi.World(mode=capi.MODE_CONTACTS) as w:
+    w.set_polytopes(capi.scene_polytopes(capi.SCENE_BOXES_DROP))
+    w.upload(bodies, sid)
+    for _ in range(5):
+        w.step(1 / 60, 4)
+    one = w.download()
+print(json.dumps({"same": bool(np.array_equal(got.view(np.uint64), one.view(np.uint64))), "lib": capi.comm_library(), "sum": float(t.sum())}))
+dist.destroy_process_group()
+''' % (str(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))),
+       str(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    script = tmp_path / "child.py"
+    script.write_text(code)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["same"] and res["sum"] == 4.0 and res["lib"]
+    print("RCCL bound from", res["lib"])
