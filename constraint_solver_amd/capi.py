@@ -101,6 +101,8 @@ MANIFOLD_DTYPE = np.dtype([("n_points", "<u4"), ("feature", "<u4"), ("index_a", 
 
 def _load(name):
     path = os.path.join(LIB_DIR, name)
+    if name == "libxpbd_hip.so" and os.environ.get("XPBD_HIP_LIB"):     # A/B measurements of kernel variants (scripts/)
+        path = os.environ["XPBD_HIP_LIB"]
     if not os.path.exists(path):
         raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(no CPU fallback exists)" % path)

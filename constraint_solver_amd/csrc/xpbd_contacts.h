@@ -46,9 +46,9 @@ struct ContactBuffers {
     uint32_t *nbr_pair;     // [entries] pair index of (min, max)
     uint32_t *pairs;        // [n_pairs][2]
     // per substep
-    double *frame_p1;       // [7][stride] post-integrate frame: origin xyz, rotation s x y z
-    double *frame_past;     // [7][stride] frame before integrate
-    double *past_pos;       // [3][stride] position before integrate (for derive)
+    double *rec;            // [stride][kRecDoubles] BodyRecord of this substep (xpbd_device.hpp): frames before / after
+                            //   integrate, pose after the ground contacts, position before integrate
+    const double *stat_rec; // [stride][kStatRecDoubles] StatRecord: inverse mass, inverse inertia, centre of mass
     ContactManifold *manifolds; // [n_pairs]
     unsigned long long *stats; // [2] touching pairs, manifold points (summed over substeps)
     uint32_t *scan_scratch; // block totals of the scans
@@ -67,27 +67,30 @@ hipError_t launch_neighbour_count(const BodyArrays &b, const ContactBuffers &c, 
 hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, hipStream_t stream);
 
 // ---- per substep -----------------------------------------------------------------------------------
-// integrate + remember frames + ground contacts (sequential per body), pose' written back to b.dyn
+// integrate + ground contacts (sequential per body): reads b.dyn, writes the body's record (frames, pose') into c.rec
 hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
                                    uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream);
 // SAT of every neighbour pair on the post-integrate frames
 // (list: NULL = pre-test inside the SAT kernel, else the two-pass form of launch_sat_pairs)
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
                                     uint32_t n_pairs, SatScratch *list, hipStream_t stream);
-// Jacobi pair solve (reads b.dyn = pose', writes dyn_out) + derive
+// Jacobi pair solve + derive: reads the records, writes all 13 dynamic fields to dyn_out (b.dyn itself is fine: nobody
+// reads another body's SoA state here)
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
                                     hipStream_t stream);
 
-// launch_pair_solve_derive of this substep and launch_integrate_ground of the next one in a single kernel: the new
-// state goes to dyn_out, the next substep's frames to the next_* arrays (a second set: the frames in `c` are still
-// being read by the other bodies).
-hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double *dyn_out, double h,
-                                              const ContactBuffers &c, double *next_frame_p1, double *next_frame_past,
-                                              double *next_past_pos, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
+// launch_pair_solve_derive of this substep and launch_integrate_ground of the next one in a single kernel: the next
+// substep's records go to next_rec (a second set: the records in `c` are still being read by the other bodies); the SoA
+// state is NOT written (the records carry everything from substep to substep; the step's last launch_pair_solve_derive
+// writes it).
+hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
+                                              double *next_rec, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
                                               hipStream_t stream);
 
-// Frames of all bodies from the SoA state into a [7][stride] array (used by the diagnostic narrowphase).
-hipError_t launch_body_frames(const BodyArrays &b, double *frames, hipStream_t stream);
+// Rigid::frame() of all bodies from the SoA state into the post-integrate frame of their records (all the diagnostic
+// narrowphase entry points need); and the StatRecords from the SoA static fields (after an upload).
+hipError_t launch_body_frames(const BodyArrays &b, double *rec, hipStream_t stream);
+hipError_t launch_stat_records(const BodyArrays &b, double *stat_rec, hipStream_t stream);
 // ... and body-major, frames[7 * i + f], for the host read-back.
 hipError_t launch_body_frames_aos(const BodyArrays &b, double *frames, hipStream_t stream);
 

@@ -512,24 +512,39 @@ __global__ void __launch_bounds__(kBlock) k_integrate_ground(BodyArrays b, Shape
     const double compliance = 1e-6 / (h * h);
 
     const SubstepFrames f = integrate_body(d, s, h);
-    store_frame(c.frame_past, st, i, f.past);
-    store_frame(c.frame_p1, st, i, f.cur);
-    store3(c.past_pos, 0, st, i, f.past_pos);
     const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
 
-    // pose after the ground contacts; velocities are rewritten by derive in k_pair_solve_derive
-    store3(b.dyn, D_POS, st, i, d.pos);
-    store_quat(b.dyn, D_ROT, st, i, d.rot);
+    // the pose after the ground contacts lives in the record only: the pair solve (the one reader) takes it from there and
+    // rewrites the whole SoA state (velocities come from derive)
+    store_record(c.rec, i, f.cur, f.past, d.pos, d.rot, f.past_pos);
     last_mask[i] = mask;
     if (TRACE)
         trace_masks[(size_t)trace_row * st + i] = mask;
 }
 
-__global__ void k_body_frames(BodyArrays b, double *__restrict__ frames)
+__global__ void k_body_frames(BodyArrays b, double *__restrict__ rec)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < b.n)
-        store_frame(frames, b.stride, i, body_frame(b, i));
+        store_record_p1(rec, i, body_frame(b, i));
+}
+
+__global__ void k_stat_records(BodyArrays b, double *__restrict__ stat_rec)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n)
+        return;
+    const uint32_t st = b.stride;
+    double v[kStatRecDoubles] = {};
+    v[0] = b.stat[(size_t)S_INV_MASS * st + i];
+    for (uint32_t k = 0; k < 9; ++k)
+        v[1 + k] = b.stat[(size_t)(S_INV_INERTIA + k) * st + i];
+    for (uint32_t k = 0; k < 3; ++k)
+        v[10 + k] = b.stat[(size_t)(S_COM + k) * st + i];
+    double2 *r = reinterpret_cast<double2 *>(stat_rec + (size_t)i * kStatRecDoubles);
+#pragma unroll
+    for (uint32_t k = 0; k < kStatRecDoubles / 2; ++k)
+        r[k] = double2{v[2 * k], v[2 * k + 1]};
 }
 
 // Rigid::frame() of every body, body-major (7 doubles each), staged through LDS so that the global
@@ -564,19 +579,37 @@ struct PairBody {
     Frame p1, past;
 };
 
-__device__ __forceinline__ PairBody load_pair_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i)
+// The static fields of body i for its own integrate stage: mass properties from the StatRecord it has loaded anyway, the
+// forces and torques (which nobody else reads) from the SoA arrays.
+__device__ __forceinline__ BodyStatic static_of(const BodyArrays &b, uint32_t i, double inv_mass, const Mat3 &inv_inertia, Vec3 com)
 {
     const uint32_t st = b.stride;
+    BodyStatic s;
+    s.inv_mass = inv_mass;
+    s.inv_inertia = inv_inertia;
+    s.com = com;
+    s.ext_force = load3(b.stat, S_EXT_FORCE, st, i);
+    s.int_force = load3(b.stat, S_INT_FORCE, st, i);
+    s.ext_torque = load3(b.stat, S_EXT_TORQUE, st, i);
+    s.int_torque = load3(b.stat, S_INT_TORQUE, st, i);
+    return s;
+}
+
+// (past_pos: optional, the position before integrate -- only a body's own derive needs it)
+__device__ __forceinline__ PairBody load_pair_body(const ContactBuffers &c, uint32_t i, Vec3 *past_pos = nullptr)
+{
+    const BodyRecord r = load_record(c.rec, i);         // two cache lines
+    const StatRecord s = load_stat_record(c.stat_rec, i); // one
     PairBody p;
-    p.pos = load3(b.dyn, D_POS, st, i);
-    p.rot = load_quat(b.dyn, D_ROT, st, i);
-    p.inv_mass = b.stat[(size_t)S_INV_MASS * st + i];
-    p.inv_inertia.cx = load3(b.stat, S_INV_INERTIA + 0, st, i);
-    p.inv_inertia.cy = load3(b.stat, S_INV_INERTIA + 3, st, i);
-    p.inv_inertia.cz = load3(b.stat, S_INV_INERTIA + 6, st, i);
-    p.com = load3(b.stat, S_COM, st, i);
-    p.p1 = load_frame(c.frame_p1, st, i);
-    p.past = load_frame(c.frame_past, st, i);
+    p.pos = r.pos;
+    p.rot = r.rot;
+    p.inv_mass = s.inv_mass;
+    p.inv_inertia = s.inv_inertia;
+    p.com = s.com;
+    p.p1 = r.p1;
+    p.past = r.past;
+    if (past_pos)
+        *past_pos = r.past_pos;
     return p;
 }
 
@@ -603,11 +636,10 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
 // added on every lane in point order -- the same values in the same order, so the same bits.
 template <uint32_t G>
 __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i, double h,
-                                                              const PairBody &self, uint32_t sub, uint32_t &touching,
+                                                              const PairBody &self, Vec3 self_past_pos, uint32_t sub, uint32_t &touching,
                                                               uint32_t &points)
 {
     static_assert(G == 1 || G == kMaxManifoldPoints, "one lane per body or one lane per manifold point");
-    const uint32_t st = b.stride;
     const double compliance = 1e-6 / (h * h);
 
     Vec3 dpos{0.0, 0.0, 0.0};
@@ -636,7 +668,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
             ++touching;
             points += n_points;
         }
-        const PairBody other = load_pair_body(b, c, j);
+        const PairBody other = load_pair_body(c, j);
         // pair (A, B) = (min, max); the reference body is A unless the reference face is on B.  The formulas are
         // written in terms of the incident and the reference body; here every term is evaluated for `self` and
         // `other` with their own point and only 3-vectors are selected by role -- selecting whole bodies by a
@@ -697,7 +729,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
         for (uint32_t k = c.joint_off[i]; k < c.joint_off[i + 1]; ++k) {
             const Joint &jt = c.joints[c.joint_list[k]];
             const bool self_is_a = jt.body_a == i;
-            const PairBody other = load_pair_body(b, c, self_is_a ? jt.body_b : jt.body_a);
+            const PairBody other = load_pair_body(c, self_is_a ? jt.body_b : jt.body_a);
             // as above: evaluate per body, select 3-vectors by role (a / b)
             const Vec3 anchor_self = self_is_a ? Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]} : Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]};
             const Vec3 anchor_other = self_is_a ? Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]} : Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]};
@@ -727,7 +759,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
         d.pos = self.pos + dpos / cnt;
         d.rot = normalized(self.rot + Quat{drot.s / cnt, drot.x / cnt, drot.y / cnt, drot.z / cnt});
     }
-    derive_body(d, load3(c.past_pos, 0, st, i), self.past.rotation, h);
+    derive_body(d, self_past_pos, self.past.rotation, h);
     return d;
 }
 
@@ -765,8 +797,9 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, i = gid / G, sub = gid % G;
     uint32_t touching = 0, points = 0;
     if (i < b.n) {
-        const PairBody self = load_pair_body(b, c, i);
-        const BodyDynamic d = pair_solve_derive_body<G>(b, c, i, h, self, sub, touching, points);
+        Vec3 past_pos;
+        const PairBody self = load_pair_body(c, i, &past_pos);
+        const BodyDynamic d = pair_solve_derive_body<G>(b, c, i, h, self, past_pos, sub, touching, points);
         if (sub == 0)
             store_dynamic(dyn_out, b.stride, i, d);
     }
@@ -783,8 +816,7 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
 // lanes and lane 0 stores.)
 template <bool TRACE, uint32_t G>
 __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_integrate_ground(
-    BodyArrays b, ShapeTable shapes, double *__restrict__ dyn_out, double h, ContactBuffers c, double *__restrict__ next_frame_p1,
-    double *__restrict__ next_frame_past, double *__restrict__ next_past_pos, uint32_t *__restrict__ last_mask,
+    BodyArrays b, ShapeTable shapes, double h, ContactBuffers c, double *__restrict__ next_rec, uint32_t *__restrict__ last_mask,
     uint32_t *__restrict__ trace_masks, uint32_t trace_row)
 {
     extern __shared__ double lds[]; // shape vertex tables, as in k_integrate_ground
@@ -800,27 +832,22 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
     if (i < b.n) {
         const uint32_t st = b.stride;
         BodyDynamic d;
+        BodyStatic s;
         {
-            const PairBody self = load_pair_body(b, c, i);
-            d = pair_solve_derive_body<G>(b, c, i, h, self, sub, touching, points);
+            Vec3 past_pos;
+            const PairBody self = load_pair_body(c, i, &past_pos);
+            d = pair_solve_derive_body<G>(b, c, i, h, self, past_pos, sub, touching, points);
+            s = static_of(b, i, self.inv_mass, self.inv_inertia, self.com);
         }
-        const Vec3 derived_vel = d.vel, derived_ang = d.ang; // what memory holds between substeps (k_integrate_ground keeps
-                                                              // its integrated velocities in registers only)
-        const BodyStatic s = load_static(b, i);
         const uint32_t sid = b.shape_id[i];
         const uint32_t v0 = lds_off[sid];
         const double compliance = 1e-6 / (h * h);
         const SubstepFrames f = integrate_body(d, s, h);
-        if (sub == 0) {
-            store_frame(next_frame_past, st, i, f.past);
-            store_frame(next_frame_p1, st, i, f.cur);
-            store3(next_past_pos, 0, st, i, f.past_pos);
-        }
         const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
-        d.vel = derived_vel;
-        d.ang = derived_ang;
         if (sub == 0) {
-            store_dynamic(dyn_out, st, i, d);
+            // everything the next kernel needs of this body is its record: no SoA state is written between the substeps of
+            // a step call (the last substep's k_pair_solve_derive writes all 13 dynamic fields)
+            store_record(next_rec, i, f.cur, f.past, d.pos, d.rot, f.past_pos);
             last_mask[i] = mask;
             if (TRACE)
                 trace_masks[(size_t)trace_row * st + i] = mask;
@@ -975,7 +1002,7 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
                                     uint32_t n_pairs, SatScratch *list, hipStream_t stream)
 {
-    return launch_sat_contacts(b, t, c.frame_p1, c.pairs, n_pairs, c.manifolds, list, stream);
+    return launch_sat_contacts(b, t, c.rec, c.pairs, n_pairs, c.manifolds, list, stream);
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
@@ -991,9 +1018,8 @@ hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double
     return hipGetLastError();
 }
 
-hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double *dyn_out, double h,
-                                              const ContactBuffers &c, double *next_frame_p1, double *next_frame_past,
-                                              double *next_past_pos, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
+hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
+                                              double *next_rec, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
                                               hipStream_t stream)
 {
     if (b.n == 0)
@@ -1002,7 +1028,7 @@ hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTa
     auto launch = [&](auto trace, auto lanes) {
         constexpr uint32_t G = decltype(lanes)::value;
         hipLaunchKernelGGL((k_pair_solve_integrate_ground<decltype(trace)::value, G>), dim3(blocks_for(b.n * G)), dim3(kBlock), lds_bytes,
-                           stream, b, s, dyn_out, h, c, next_frame_p1, next_frame_past, next_past_pos, last_mask, trace_masks, trace_row);
+                           stream, b, s, h, c, next_rec, last_mask, trace_masks, trace_row);
     };
     using Wide = std::integral_constant<uint32_t, kMaxManifoldPoints>;
     using One = std::integral_constant<uint32_t, 1>;
@@ -1055,10 +1081,17 @@ hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices
     return hipGetLastError();
 }
 
-hipError_t launch_body_frames(const BodyArrays &b, double *frames, hipStream_t stream)
+hipError_t launch_body_frames(const BodyArrays &b, double *rec, hipStream_t stream)
 {
     if (b.n)
-        hipLaunchKernelGGL(k_body_frames, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, frames);
+        hipLaunchKernelGGL(k_body_frames, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, rec);
+    return hipGetLastError();
+}
+
+hipError_t launch_stat_records(const BodyArrays &b, double *stat_rec, hipStream_t stream)
+{
+    if (b.n)
+        hipLaunchKernelGGL(k_stat_records, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, stat_rec);
     return hipGetLastError();
 }
 

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     Frame fa{}, fb{};
     if (live) {
         ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
-        fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
+        fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
         sa = b.shape_id[ia], sb = b.shape_id[ib];
         da = t.desc[sa], db = t.desc[sb];
     }
@@ -351,7 +351,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
                                          GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint32_t lane)
 {
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
-    const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
+    const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
     const ShapeDesc da = t.desc[b.shape_id[ia]], db = t.desc[b.shape_id[ib]];
     const uint32_t na = da.n_verts, nb = db.n_verts;
     GjkResult *r = out ? out + p : nullptr;

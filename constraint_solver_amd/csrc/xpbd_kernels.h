@@ -28,6 +28,10 @@ enum StatField : uint32_t {
     S_EXT_TORQUE = 16, S_INT_TORQUE = 19, S_COM = 22
 };
 
+// Body-major records of the contact pipeline (layout and rationale: xpbd_device.hpp), in doubles per body.
+constexpr uint32_t kRecDoubles = 24;
+constexpr uint32_t kStatRecDoubles = 16;
+
 struct BodyArrays {
     double *dyn;        // kDynFields  * stride doubles
     double *stat;       // kStatFields * stride doubles

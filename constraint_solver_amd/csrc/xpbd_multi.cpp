@@ -243,6 +243,9 @@ template <class Send, class Recv>
 int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv recv_of)
 {
     if (mw->transport == XPBD_TRANSPORT_RCCL) {
+        // RCCL reads the thread's last HIP error after its own calls: a stale, harmless one left by somebody else in the
+        // process (hipErrorNotReady from an event query, say) would be reported as "unhandled cuda error"
+        (void)hipGetLastError();
         ncclResult_t r = mw->rccl->GroupStart();
         if (r != ncclSuccess)
             return nccl_fail(mw, r, "ncclGroupStart");
@@ -580,6 +583,7 @@ int xpbd_comm_unique_id(uint8_t id[XPBD_COMM_ID_BYTES])
     if (!api)
         return set_error(XPBD_E_NO_DEVICE, "xpbd_comm_unique_id: RCCL is not available (%s)", why);
     ncclUniqueId u;
+    (void)hipGetLastError(); // see all_gather_device
     const ncclResult_t r = api->GetUniqueId(&u);
     if (r != ncclSuccess)
         return set_error(XPBD_E_HIP, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
@@ -671,6 +675,7 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
     if (mw->transport == XPBD_TRANSPORT_RCCL) {
         ncclUniqueId id;
         std::memcpy(&id, cfg->comm_id, sizeof id);
+        (void)hipGetLastError(); // see all_gather_device
         ncclResult_t r = mw->rccl->GroupStart();
         for (Shard &s : mw->shards) {
             if (r != ncclSuccess)

@@ -50,8 +50,8 @@ struct Manifold {
     double p_inc[kMaxManifoldPoints][3];
 };
 
-// pairs[2*p], pairs[2*p+1] are body indices (A, B); 16, 32 or 64 lanes per pair.  frames: [7][stride] object->world
-// frames of all bodies (origin xyz, rotation s x y z).
+// pairs[2*p], pairs[2*p+1] are body indices (A, B); 8, 16, 32 or 64 lanes per pair.  frames: the bodies' BodyRecords
+// (xpbd_device.hpp), of which the narrowphase reads the post-integrate frame (the first 56 bytes: one cache line).
 // The same result as the contact pipeline stores it: points interleaved (incident, reference) so that the usual
 // manifold of <= 4 points is the first 208 bytes, records 512-byte aligned -- the pair solve reads every manifold
 // twice, and with the 408-byte public layout (p_ref block, then p_inc block, unaligned) a 4-point manifold touched

@@ -173,7 +173,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
                                               // launcher uses L = 8 only where no polygon can exceed 8 vertices)
     // ---- group-uniform inputs ---------------------------------------------------------------------
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
-    const Frame fa = load_frame(frames, b.stride, ia), fb = load_frame(frames, b.stride, ib);
+    const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
     const Frame fa_inv = inverse(fa), fb_inv = inverse(fb);
     const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
     const ShapeDesc da = t.desc[sa], db = t.desc[sb];
@@ -464,7 +464,7 @@ __device__ __forceinline__ bool tight_spheres_overlap(const BodyArrays &b, const
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
     const double *ca = t.centroids + 3 * (size_t)sa, *cb = t.centroids + 3 * (size_t)sb;
-    const Vec3 between = load_frame(frames, b.stride, ib) * Vec3{cb[0], cb[1], cb[2]} - load_frame(frames, b.stride, ia) * Vec3{ca[0], ca[1], ca[2]};
+    const Vec3 between = load_record_p1(frames, ib) * Vec3{cb[0], cb[1], cb[2]} - load_record_p1(frames, ia) * Vec3{ca[0], ca[1], ca[2]};
     const double reach = t.radii[sa] + t.radii[sb];
     return dot(between, between) < reach * reach;
 }

@@ -1,4 +1,7 @@
 // xpbd_rccl.cpp -- see xpbd_rccl.h.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE // dladdr
+#endif
 #include "xpbd_rccl.h"
 
 #include <cstdlib>
@@ -31,6 +34,20 @@ bool bind(void *h, const char *path)
     return true;
 }
 
+// Directory of the HIP runtime this library is running on.  RCCL opens the HSA runtime by its unversioned file name, found
+// through RCCL's own run path: a process can hold two ROCm trees (the system's and the one PyTorch bundles) with only one
+// of them initialised -- whichever was loaded first -- and an RCCL from the OTHER tree then opens a second, uninitialised
+// copy of the HSA runtime and fails with "no ROCm-capable device".  So RCCL is taken from the tree of the active runtime.
+std::string active_runtime_dir()
+{
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) || !info.dli_fname)
+        return "";
+    const std::string path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    return slash == std::string::npos ? "" : path.substr(0, slash);
+}
+
 void load_once()
 {
     struct Try {
@@ -38,8 +55,12 @@ void load_once()
         int flags;
     };
     const char *env = std::getenv("XPBD_RCCL_LIB");
+    const std::string dir = active_runtime_dir();
+    const std::string beside1 = dir.empty() ? "" : dir + "/librccl.so.1", beside = dir.empty() ? "" : dir + "/librccl.so";
     const Try tries[] = {
         {env, RTLD_NOW | RTLD_LOCAL},
+        {beside1.c_str(), RTLD_NOW | RTLD_LOCAL},
+        {beside.c_str(), RTLD_NOW | RTLD_LOCAL},
         {"librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD},
         {"librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD},
         {"librccl.so.1", RTLD_NOW | RTLD_LOCAL},

@@ -18,8 +18,9 @@ struct RcclApi {
     const char *path = ""; // what was opened
 };
 
-// The process-wide binding, or nullptr with *why set.  Search order: $XPBD_RCCL_LIB, a copy already loaded into the
-// process (librccl.so.1, librccl.so), then librccl.so.1 / librccl.so on the loader path, then /opt/rocm/lib.
+// The process-wide binding, or nullptr with *why set.  Search order: $XPBD_RCCL_LIB, librccl next to the HIP runtime this
+// library runs on (see xpbd_rccl.cpp: it must come from the same ROCm tree), a copy already loaded into the process, then
+// librccl.so.1 / librccl.so on the loader path, then /opt/rocm/lib.
 const RcclApi *rccl_api(const char **why);
 
 } // namespace xpbd

@@ -135,10 +135,11 @@ struct xpbd_world {
     double contact_pad = 0.02;
     uint32_t narrowphase = XPBD_NARROWPHASE_SAT;
     DeviceBuffer dyn_alt, cb_centers, cb_radius, cb_cell, cb_key, cb_maxr, cb_bucket_start, cb_bucket_cursor, cb_items,
-        cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_frame_p1, cb_frame_past,
-        cb_past_pos, cb_manifolds, cb_stats, cb_scan, cb_slot_sphere, cb_slot_cell;
-    // second set of per-substep frames for the fused "end of substep k + start of substep k + 1" kernel (step_contacts)
-    DeviceBuffer cb_frame_p1_b, cb_frame_past_b, cb_past_pos_b;
+        cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_rec, cb_stat_rec,
+        cb_manifolds, cb_stats, cb_scan, cb_slot_sphere, cb_slot_cell;
+    // second set of per-substep records for the fused "end of substep k + start of substep k + 1" kernel (step_contacts)
+    DeviceBuffer cb_rec_b;
+    bool stat_rec_valid = false; // the StatRecords mirror the SoA static fields of the bodies uploaded last
     DeviceBuffer cb_grid_partials, cb_items_unsorted;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
@@ -181,9 +182,8 @@ struct xpbd_world {
         c.nbr = cb_nbr.as<uint32_t>();
         c.nbr_pair = cb_nbr_pair.as<uint32_t>();
         c.pairs = cb_pairs.as<uint32_t>();
-        c.frame_p1 = (frame_set ? cb_frame_p1_b : cb_frame_p1).as<double>();
-        c.frame_past = (frame_set ? cb_frame_past_b : cb_frame_past).as<double>();
-        c.past_pos = (frame_set ? cb_past_pos_b : cb_past_pos).as<double>();
+        c.rec = (frame_set ? cb_rec_b : cb_rec).as<double>();
+        c.stat_rec = cb_stat_rec.as<double>();
         c.manifolds = cb_manifolds.as<xpbd::ContactManifold>();
         c.stats = cb_stats.as<unsigned long long>();
         c.scan_scratch = cb_scan.as<uint32_t>();
@@ -255,12 +255,15 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_nbr_off.reserve((size_t)(st + 1) * 4));
     XPBD_HIP_TRY(w->cb_pair_first.reserve((size_t)(st + 1) * 4));
     XPBD_HIP_TRY(w->cb_upper_start.reserve((size_t)st * 4));
-    XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * st * 8));
-    XPBD_HIP_TRY(w->cb_frame_past.reserve((size_t)7 * st * 8));
-    XPBD_HIP_TRY(w->cb_past_pos.reserve((size_t)3 * st * 8));
-    XPBD_HIP_TRY(w->cb_frame_p1_b.reserve((size_t)7 * st * 8));
-    XPBD_HIP_TRY(w->cb_frame_past_b.reserve((size_t)7 * st * 8));
-    XPBD_HIP_TRY(w->cb_past_pos_b.reserve((size_t)3 * st * 8));
+    XPBD_HIP_TRY(w->cb_rec.reserve((size_t)xpbd::kRecDoubles * st * 8));
+    XPBD_HIP_TRY(w->cb_rec_b.reserve((size_t)xpbd::kRecDoubles * st * 8));
+    if (w->cb_stat_rec.bytes < (size_t)xpbd::kStatRecDoubles * st * 8)
+        w->stat_rec_valid = false;
+    XPBD_HIP_TRY(w->cb_stat_rec.reserve((size_t)xpbd::kStatRecDoubles * st * 8));
+    if (!w->stat_rec_valid) {
+        XPBD_HIP_TRY(xpbd::launch_stat_records(w->arrays(), w->cb_stat_rec.as<double>(), w->stream));
+        w->stat_rec_valid = true;
+    }
     XPBD_HIP_TRY(w->cb_scan.reserve(((size_t)(w->table_size > st ? w->table_size : st) / 1024 + 8) * 4));
     if (!w->cb_stats.ptr) {
         XPBD_HIP_TRY(w->cb_stats.reserve(16));
@@ -319,7 +322,7 @@ int narrowphase_contacts(xpbd_world *w, const xpbd::BodyArrays &b, const xpbd::C
     if (w->narrowphase == XPBD_NARROWPHASE_GJK_EPA) {
         if (int rc = ensure_gjk_scratch(w, w->n_pairs))
             return rc;
-        XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.frame_p1, c.pairs, w->n_pairs, nullptr, c.manifolds,
+        XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.rec, c.pairs, w->n_pairs, nullptr, c.manifolds,
                                                 w->gjk_scratch, true, w->sat_two_pass ? &w->sat_scratch : nullptr, w->stream));
     } else {
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
@@ -338,14 +341,15 @@ int substep_contacts(xpbd_world *w, double h, uint32_t *trace, uint32_t trace_ro
     XPBD_HIP_TRY(xpbd::launch_integrate_ground(b, w->shapes(), h, c, w->last_mask.as<uint32_t>(), trace, trace_row, w->stream));
     if (int rc = narrowphase_contacts(w, b, c))
         return rc;
-    XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
-    std::swap(w->dyn, w->dyn_alt);
+    XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, b.dyn, h, c, w->stream));
     return XPBD_OK;
 }
 
 // One xpbd_world_step in XPBD_MODE_CONTACTS (semantics: oracle/xpbd_pairs_oracle.h).  All substeps run here, so the
-// pair solve of substep k and the integrate + ground stage of substep k + 1 are one kernel; the frames alternate
-// between two sets because the bodies still read each other's frames of substep k while those of k + 1 are written.
+// pair solve of substep k and the integrate + ground stage of substep k + 1 are one kernel; the body records alternate
+// between two sets because the bodies still read each other's records of substep k while those of k + 1 are written.
+// Between the substeps the state lives in the records only; the SoA arrays are read by the first kernel and written by
+// the last.
 int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_t *trace)
 {
     if (!w->has_topology)
@@ -363,13 +367,11 @@ int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_
             return rc;
         if (k + 1 < substeps) {
             const xpbd::ContactBuffers next = w->contact_buffers((k + 1u) & 1u);
-            XPBD_HIP_TRY(xpbd::launch_pair_solve_integrate_ground(b, w->shapes(), w->dyn_alt.as<double>(), h, c, next.frame_p1,
-                                                                  next.frame_past, next.past_pos, w->last_mask.as<uint32_t>(), trace,
+            XPBD_HIP_TRY(xpbd::launch_pair_solve_integrate_ground(b, w->shapes(), h, c, next.rec, w->last_mask.as<uint32_t>(), trace,
                                                                   k + 1, w->stream));
         } else {
-            XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, w->dyn_alt.as<double>(), h, c, w->stream));
+            XPBD_HIP_TRY(xpbd::launch_pair_solve_derive(b, b.dyn, h, c, w->stream));
         }
-        std::swap(w->dyn, w->dyn_alt);
     }
     return XPBD_OK;
 }
@@ -465,10 +467,10 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->manifold_buf, &w->shape_radii, &w->edge_dirs, &w->edge_dir_id, &w->dyn_alt, &w->cb_centers, &w->cb_radius, &w->cb_cell,
                             &w->cb_key, &w->cb_maxr, &w->cb_bucket_start, &w->cb_bucket_cursor, &w->cb_items,
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
-                            &w->cb_pairs, &w->cb_frame_p1, &w->cb_frame_past, &w->cb_past_pos, &w->cb_manifolds,
+                            &w->cb_pairs, &w->cb_rec, &w->cb_stat_rec, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
-                            &w->sat_counters, &w->sat_survivors, &w->cb_frame_p1_b, &w->cb_frame_past_b, &w->cb_past_pos_b,
+                            &w->sat_counters, &w->sat_survivors, &w->cb_rec_b,
                             &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
     if (w->own_stream)
@@ -651,9 +653,9 @@ int xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pair
     XPBD_HIP_TRY(w->manifold_buf.reserve((size_t)n_pairs * sizeof(xpbd::Manifold)));
     XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
     XPBD_HIP_TRY(hipMemsetAsync(w->manifold_buf.ptr, 0, (size_t)n_pairs * sizeof(xpbd::Manifold), w->stream));
-    XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * w->stride * 8));
-    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
-    XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(), w->pair_buf.as<uint32_t>(),
+    XPBD_HIP_TRY(w->cb_rec.reserve((size_t)xpbd::kRecDoubles * w->stride * 8));
+    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_rec.as<double>(), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_sat_pairs(w->arrays(), w->tables(), w->cb_rec.as<double>(), w->pair_buf.as<uint32_t>(),
                                         n_pairs, w->manifold_buf.as<xpbd::Manifold>(), w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::Manifold),
                                 hipMemcpyDeviceToHost, w->stream));
@@ -680,7 +682,6 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     const uint32_t stride = round_up(n ? n : 1, 256);
     XPBD_HIP_TRY(w->dyn.reserve((size_t)xpbd::kDynFields * stride * 8));
-    XPBD_HIP_TRY(w->dyn_alt.reserve((size_t)xpbd::kDynFields * stride * 8));
     w->have_neighbours = false;
     w->n_joints = 0; // joints name bodies by index: a new upload invalidates them
     w->history_length = 0;
@@ -691,6 +692,7 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     XPBD_HIP_TRY(w->aos_staging.reserve((size_t)(n ? n : 1) * sizeof(xpbd_rigid)));
     w->n = n;
     w->stride = stride;
+    w->stat_rec_valid = false;
     w->max_shape_id = max_shape_id;
     w->stepped = false;
     w->trace_rows = 0;
@@ -907,13 +909,13 @@ int xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_
     XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
     XPBD_HIP_TRY(w->pair_buf.reserve((size_t)n_pairs * 8));
     XPBD_HIP_TRY(w->manifold_buf.reserve((size_t)n_pairs * sizeof(xpbd::GjkResult)));
-    XPBD_HIP_TRY(w->cb_frame_p1.reserve((size_t)7 * w->stride * 8));
+    XPBD_HIP_TRY(w->cb_rec.reserve((size_t)xpbd::kRecDoubles * w->stride * 8));
     XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
     XPBD_HIP_TRY(hipMemsetAsync(w->manifold_buf.ptr, 0, (size_t)n_pairs * sizeof(xpbd::GjkResult), w->stream));
-    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_frame_p1.as<double>(), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_rec.as<double>(), w->stream));
     if (int rc = ensure_gjk_scratch(w, n_pairs))
         return rc;
-    XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_frame_p1.as<double>(),
+    XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(w->arrays(), w->tables(), w->cb_rec.as<double>(),
                                             w->pair_buf.as<uint32_t>(), n_pairs, w->manifold_buf.as<xpbd::GjkResult>(),
                                             nullptr, w->gjk_scratch, false, nullptr, w->stream));
     XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::GjkResult), hipMemcpyDeviceToHost,
