@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_import_dynamic_rows", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
     "xpbd_world_set_sat_schedule",
+    "xpbd_world_edge_axes_separation",
     "xpbd_selftest_hbm_copy", "xpbd_world_snapshot_positions", "xpbd_world_max_displacement2",
     "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
     "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
@@ -91,6 +92,8 @@ JOINT_DTYPE = np.dtype([("body_a", "<u4"), ("body_b", "<u4"), ("anchor_a", "<f8"
 GJK_DTYPE = np.dtype([("status", "<i4"), ("gjk_iterations", "<u4"), ("epa_iterations", "<u4"), ("reserved", "<u4"),
                       ("depth", "<f8"), ("normal", "<f8", (3,)), ("point_a", "<f8", (3,)), ("point_b", "<f8", (3,))])
 GJK_SEPARATED, GJK_PENETRATING, GJK_DEGENERATE = 0, 1, 2
+# xpbd_edge_query as a numpy record (16 bytes)
+EDGE_QUERY_DTYPE = np.dtype([("separation", "<f8"), ("edge_a", "<u4"), ("edge_b", "<u4")])
 NARROWPHASE_SAT, NARROWPHASE_GJK_EPA = 0, 1
 MAX_MANIFOLD_POINTS = 8
 FEATURE_FACE_A, FEATURE_FACE_B, FEATURE_EDGES = 0, 1, 2
@@ -164,6 +167,7 @@ def hip_lib():
                                      _u32p, C.c_uint32]
         L.xpbd_world_set_polytopes.argtypes = [C.c_void_p, C.POINTER(PolytopeDesc), C.c_uint32]
         L.xpbd_world_narrowphase.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
+        L.xpbd_world_edge_axes_separation.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         L.xpbd_world_narrowphase_gjk.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         L.xpbd_world_set_narrowphase.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_world_set_contact_pad.argtypes = [C.c_void_p, C.c_double]
@@ -303,6 +307,13 @@ class World:
         pr = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
         out = np.zeros(pr.shape[0], dtype=MANIFOLD_DTYPE)
         _check(hip_lib().xpbd_world_narrowphase(self._h, _u32(pr), pr.shape[0], out.ctypes.data))
+        return out
+
+    def edge_axes_separation(self, pairs):
+        """The reference's edge_axes_separation (src/collision.rs:151-197) of the given (A, B) pairs: EDGE_QUERY_DTYPE records."""
+        pr = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros(pr.shape[0], dtype=EDGE_QUERY_DTYPE)
+        _check(hip_lib().xpbd_world_edge_axes_separation(self._h, _u32(pr), pr.shape[0], out.ctypes.data))
         return out
 
     def narrowphase_gjk(self, pairs):

@@ -65,6 +65,15 @@ struct alignas(512) ContactManifold {
 };
 static_assert(sizeof(ContactManifold) == 512, "one contact manifold = four cache lines, the first two hold <= 4 points");
 
+// Result of the reference's edge_axes_separation for one pair (xpbd_edge_query in include/xpbd.h has this layout).
+struct EdgeQuery {
+    double separation;      // f64::MIN (-DBL_MAX) when no edge pair qualified
+    uint32_t edge_a, edge_b; // usize::MAX there, 0xFFFFFFFF here, when none
+};
+// edge_axes_separation literally as in src/collision.rs:151-197 (diagnostic; one wave per pair).
+hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                                      uint32_t n_pairs, EdgeQuery *out, hipStream_t stream);
+
 // (The pipeline's statistics -- touching pairs, contact points -- are summed by the pair solve, xpbd_contacts.hip.)
 
 // Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two uint32, zero when

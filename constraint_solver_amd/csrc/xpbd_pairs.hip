@@ -45,14 +45,21 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kWidePairCount = 32768; // 8 pairs per wave x 4 096 wave slots (1 024 SIMDs x 4)
 
 // Working set of one pair.  V = vertex capacity per body, P = polygon capacity of the clipper (the launcher picks the
-// group width and both from the largest shape).  The tail pads the record so that its stride
-// staggers the records of the PW pairs of a wave over the LDS banks -- all groups read "vertex k of my pair" in the
-// same instruction, and records a multiple of 64 dwords apart would put those reads on the same banks (measured:
-// SQ_LDS_BANK_CONFLICT = 86 % of the LDS cycles).
+// group width and both from the largest shape).  Two halves: the world-space vertices, and a scratch area that is, in
+// turn, the vertices in the other body's local space (face queries), the world-space edge directions (edge axes) and
+// the clipper's ping-pong polygons; the reference face's vertices take the place of the INCIDENT body's world-space
+// vertices once the incident face has been copied out.  The kernel is bound by latency (LDS round trips, shuffles), so
+// what counts is how many waves a CU holds: with everything side by side (1 376 bytes per box pair, eight pairs per
+// wave) the LDS allowed 14 waves per CU, now (800 bytes) 25.
+// The tail pads the record so that its stride staggers the records of the PW pairs of a wave over the LDS banks -- all
+// groups read "vertex k of my pair" in the same instruction, and records a multiple of 64 dwords apart would put those
+// reads on the same banks (measured: SQ_LDS_BANK_CONFLICT = 86 % of the LDS cycles).
 template <uint32_t V, uint32_t P, uint32_t PW>
 struct PairLds {
     static constexpr uint32_t kVerts = V;
-    static constexpr uint32_t kBaseDwords = 2 * (2 * 2 * V * 3 + 2 * P * 3 + kMaxFaceVerts * 3);
+    static_assert(kMaxFaceVerts <= V, "the reference face reuses vertex rows");
+    static constexpr uint32_t kScratchRows = P > V ? P : V;
+    static constexpr uint32_t kBaseDwords = 2 * (2 * V * 3 + 2 * kScratchRows * 3);
     // record stride = an ODD multiple of 64 / PW dwords (mod 64): the PW records then start on PW different bank
     // groups; of the candidates take the one that needs the least padding
     static constexpr uint32_t pad_dwords()
@@ -68,9 +75,10 @@ struct PairLds {
     }
     static constexpr uint32_t kPadDwords = pad_dwords();
     double world[2][V][3]; // world-space vertices of A (0) and B (1)
-    double local[2][V][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space
-    double poly[2][P][3];  // clipping ping-pong
-    double ref[kMaxFaceVerts][3]; // the reference face's vertices, staged once for the clipping loop
+    union {
+        double local[2][V][3]; // [0]: A's vertices in B-local space, [1]: B's vertices in A-local space; then the edge directions
+        double poly[2][P][3];  // clipping ping-pong
+    };
     uint32_t pad[kPadDwords ? kPadDwords : 2];
 };
 
@@ -389,17 +397,27 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
     const uint32_t *iv = t.face_verts + t.face_start[di.face0 + iface];
     uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
+    // (the block is one wave and its LDS accesses execute in program order: every lane's read of an instruction has been
+    // issued before any lane's write of a later one, so the polygons may overwrite the edge directions they alias and the
+    // reference face the incident body's vertices)
+    Vec3 inc_vertex{0.0, 0.0, 0.0}, ref_vertex{0.0, 0.0, 0.0};
     if (lane < np)
-        st3(s.poly[0], lane, ld3(s.world[r ^ 1u], iv[lane]));
+        inc_vertex = ld3(s.world[r ^ 1u], iv[lane]);
+    if (lane < nr && lane < kMaxFaceVerts)
+        ref_vertex = ld3(s.world[r], rv[lane]);
+    __syncthreads();
     // the reference face's vertices by index once, lane-parallel: the clipping loop below then reads LDS only
     // (phase timing: the three dependent global index loads per side plane were ~40 % of the loop)
+    double(*const ref)[3] = s.world[r ^ 1u];
+    if (lane < np)
+        st3(s.poly[0], lane, inc_vertex);
     if (lane < nr && lane < kMaxFaceVerts)
-        st3(s.ref, lane, ld3(s.world[r], rv[lane]));
+        st3(ref, lane, ref_vertex);
     __syncthreads();
     uint32_t cur = 0;
     for (uint32_t e = 0; e < nr && np > 0; ++e) {
-        const Vec3 a = ld3(s.ref, e), bnext = ld3(s.ref, (e + 1) % nr);
-        const Vec3 c = ld3(s.ref, (e + 2) % nr);
+        const Vec3 a = ld3(ref, e), bnext = ld3(ref, (e + 1) % nr);
+        const Vec3 c = ld3(ref, (e + 2) % nr);
         Vec3 side = cross(bnext - a, ref_plane.normal);
         if (dot(side, c - a) > 0.0)
             side = -side;
@@ -560,6 +578,75 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
     sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[k], out, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// edge_axes_separation AS THE REFERENCE WROTE IT (src/collision.rs:151-197; uncalled there, even by `sat`): every edge of A
+// against every edge of B (144 pairs for boxes), axis = normalize(eA x eB) turned away from A's centroid, the pair is
+// skipped when A has a vertex further along the axis than the edge's foot, distance of B's support along -axis from the
+// plane through the foot; the FIRST maximum in the (edge of A, edge of B) enumeration wins; parallel edges give a NaN axis
+// and contribute nothing.  A diagnostic counterpart of that function, checked against the oracle's literal
+// o_edge_axes_separation: the contact pipeline's SAT uses the unique-edge-direction test instead (sat_pair above).
+// One wave per pair; the edge pairs are strided over the lanes.
+struct EdgeLds {
+    double world[2][kMaxV][3];
+};
+
+__device__ __forceinline__ Vec3 support_last_max_position(const double (*verts)[3], uint32_t n, Vec3 dir)
+{
+    // Polytope::support (src/geometry.rs:274-281): max_by over the world-space vertices, last maximum under total_cmp
+    return support_last_max(verts, n, dir);
+}
+
+__global__ void __launch_bounds__(64) k_edge_axes_reference(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+                                                            const uint32_t *__restrict__ pairs, uint32_t n_pairs, EdgeQuery *__restrict__ out)
+{
+    __shared__ EdgeLds s;
+    const uint32_t p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n_pairs)
+        return;
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
+    const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
+    const uint32_t sa = b.shape_id[ia], sb = b.shape_id[ib];
+    const ShapeDesc da = t.desc[sa], db = t.desc[sb];
+    for (uint32_t v = lane; v < da.n_verts + db.n_verts; v += 64) {
+        const bool of_b = v >= da.n_verts;
+        const uint32_t k = of_b ? v - da.n_verts : v;
+        const double *x = t.verts + 3 * (size_t)((of_b ? db.vert0 : da.vert0) + k);
+        st3(s.world[of_b ? 1 : 0], k, (of_b ? fb : fa) * Vec3{x[0], x[1], x[2]});
+    }
+    __syncthreads();
+    const double *cca = t.centroids + 3 * (size_t)sa;
+    const Vec3 centroid_a = fa * Vec3{cca[0], cca[1], cca[2]};
+    double best = -DBL_MAX; // f64::MIN
+    uint32_t best_q = kNone;
+    const uint32_t total = da.n_edges * db.n_edges;
+    for (uint32_t q = lane; q < total; q += 64) {
+        const uint32_t ie = q / db.n_edges, je = q - ie * db.n_edges;
+        const uint32_t *ea = t.edges + 2 * (size_t)(da.edge0 + ie), *eb = t.edges + 2 * (size_t)(db.edge0 + je);
+        const Vec3 foot = ld3(s.world[0], ea[0]);
+        const Vec3 e0 = ld3(s.world[0], ea[1]) - foot;
+        const Vec3 e1 = ld3(s.world[1], eb[1]) - ld3(s.world[1], eb[0]);
+        Vec3 axis = normalized(cross(e0, e1));
+        if (dot(axis, foot - centroid_a) < 0.0)
+            axis = -axis;
+        if (da.n_verts == 0 || db.n_verts == 0)
+            continue; // the reference's .unwrap() would panic on a polytope without vertices
+        if (dot(support_last_max_position(s.world[0], da.n_verts, axis), axis) > dot(foot, axis))
+            continue;
+        const Plane plane = plane_from_point_normal(foot, axis);
+        const double dist = distance(plane, support_last_max_position(s.world[1], db.n_verts, -axis));
+        if (dist > best) { // ascending q on this lane: first maximum; a NaN never wins
+            best = dist;
+            best_q = q;
+        }
+    }
+    reduce_max_first(best, best_q, 64);
+    if (lane == 0) {
+        out[p].separation = best;
+        out[p].edge_a = best_q == kNone ? kNone : best_q / db.n_edges;
+        out[p].edge_b = best_q == kNone ? kNone : best_q % db.n_edges;
+    }
+}
+
 } // namespace
 
 namespace {
@@ -592,6 +679,14 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
             hipLaunchKernelGGL((k_sat_pairs<L, V, false, Manifold>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
                                frames, pairs, n_pairs, out);
         });
+    return hipGetLastError();
+}
+
+hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
+                                      uint32_t n_pairs, EdgeQuery *out, hipStream_t stream)
+{
+    if (n_pairs)
+        hipLaunchKernelGGL(k_edge_axes_reference, dim3(n_pairs), dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
     return hipGetLastError();
 }
 

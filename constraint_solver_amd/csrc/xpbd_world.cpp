@@ -663,6 +663,33 @@ int xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pair
     return XPBD_OK;
 }
 
+int xpbd_world_edge_axes_separation(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_edge_query *out)
+{
+    static_assert(sizeof(xpbd_edge_query) == sizeof(xpbd::EdgeQuery), "xpbd_edge_query must mirror xpbd::EdgeQuery");
+    if (!w || (n_pairs && (!pairs || !out)))
+        return fail(XPBD_E_INVALID, "xpbd_world_edge_axes_separation: NULL argument");
+    if (!w->has_topology)
+        return fail(XPBD_E_INVALID, "xpbd_world_edge_axes_separation: call xpbd_world_set_polytopes first");
+    for (uint32_t k = 0; k < 2 * n_pairs; ++k)
+        if (pairs[k] >= w->n)
+            return fail(XPBD_E_INVALID, "xpbd_world_edge_axes_separation: pair %u names body %u of %u", k / 2, pairs[k], w->n);
+    if (n_pairs == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    XPBD_HIP_TRY(w->pair_buf.reserve((size_t)n_pairs * 8));
+    XPBD_HIP_TRY(w->manifold_buf.reserve((size_t)n_pairs * sizeof(xpbd::EdgeQuery)));
+    XPBD_HIP_TRY(w->cb_rec.reserve((size_t)xpbd::kRecDoubles * w->stride * 8));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->pair_buf.ptr, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_body_frames(w->arrays(), w->cb_rec.as<double>(), w->stream));
+    XPBD_HIP_TRY(xpbd::launch_edge_axes_reference(w->arrays(), w->tables(), w->cb_rec.as<double>(), w->pair_buf.as<uint32_t>(), n_pairs,
+                                                  w->manifold_buf.as<xpbd::EdgeQuery>(), w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(out, w->manifold_buf.ptr, (size_t)n_pairs * sizeof(xpbd::EdgeQuery), hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
 int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_t *shape_id, uint32_t n)
 {
     if (!w || (!aos && n))

@@ -106,6 +106,14 @@ pub struct XpbdGjkResult {
     pub point_b: [f64; 3],
 }
 
+/// xpbd_edge_query: the reference's edge_axes_separation result, (f64::MIN, (usize::MAX, usize::MAX)) as (-DBL_MAX, !0, !0)
+#[repr(C)]
+pub struct XpbdEdgeQuery {
+    pub separation: f64,
+    pub edge_a: u32,
+    pub edge_b: u32,
+}
+
 #[repr(C)]
 pub struct XpbdWorld {
     _private: [u8; 0],
@@ -165,6 +173,7 @@ extern "C" {
     // ---- extension: body-body contacts, joints, multi-GPU halo exchange (not in the reference) ----
     pub fn xpbd_world_set_polytopes(w: *mut XpbdWorld, shapes: *const XpbdPolytope, n_shapes: u32) -> c_int;
     pub fn xpbd_world_narrowphase(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdManifold) -> c_int;
+    pub fn xpbd_world_edge_axes_separation(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdEdgeQuery) -> c_int;
     pub fn xpbd_world_narrowphase_gjk(w: *mut XpbdWorld, pairs: *const u32, n_pairs: u32, out: *mut XpbdGjkResult) -> c_int;
     pub fn xpbd_world_set_narrowphase(w: *mut XpbdWorld, narrowphase: u32) -> c_int;
     pub fn xpbd_world_set_sat_schedule(w: *mut XpbdWorld, schedule: u32) -> c_int;

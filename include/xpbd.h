@@ -196,6 +196,17 @@ int  xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32
 int  xpbd_world_narrowphase(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs,
                             xpbd_manifold *out);
 
+/* The reference's edge_axes_separation (src/collision.rs:151-197: written, but called by nobody there, not even by `sat`)
+ * for the given pairs at the world's current poses, literally: all E_A x E_B edge pairs, axis = normalize(eA x eB) turned
+ * away from A's centroid, skipped when A has a vertex beyond the edge's foot, distance of B's support along -axis; first
+ * maximum wins, parallel edges (NaN axis) contribute nothing.  Returns (f64::MIN, (usize::MAX, usize::MAX)) as
+ * (-DBL_MAX, 0xFFFFFFFF, 0xFFFFFFFF).  Diagnostic: the contact pipeline's SAT tests the unique edge DIRECTIONS instead. */
+typedef struct xpbd_edge_query {
+    double   separation;
+    uint32_t edge_a, edge_b;
+} xpbd_edge_query;
+int  xpbd_world_edge_axes_separation(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_edge_query *out);
+
 /* GJK + EPA narrowphase of the given pairs (the reference has neither): boolean GJK on the
  * Minkowski difference built with the reference's support convention (src/geometry.rs:274-289), then EPA for the
  * penetration depth, the normal (from A to B) and one witness point on each body.  16 or 32 lanes per pair

@@ -595,3 +595,36 @@ def test_contact_pipeline_on_random_hulls_with_whole_wave_groups(narrowphase):
             assert bits_equal(w.download(), want)
             touched = w.contact_stats()[1]
     assert touched > 50                                             # hulls really did collide
+
+
+@pytest.mark.parametrize("kind,n,spread", [(capi.SCENE_BOXES, 120, 1.6), (capi.SCENE_MIXED, 120, 1.0)])
+def test_reference_edge_axes_separation_on_the_device_matches_the_oracle(kind, n, spread, oracle):
+    """The reference wrote edge_axes_separation (src/collision.rs:151-197) but calls it nowhere; its literal HIP counterpart
+    (xpbd_world_edge_axes_separation: all E_A x E_B edge pairs, first maximum, NaN axes contribute nothing) against the
+    oracle's literal restatement, bit for bit -- separated, touching and axis-aligned (parallel-edge) pairs alike."""
+    bodies, sid = cluster(kind, n, 33, spread)
+    bodies[:20, 34:38] = [1.0, 0.0, 0.0, 0.0]                       # axis-aligned bodies: parallel edges give NaN axes
+    rng = np.random.default_rng(9)
+    pairs = rng.integers(0, n, (1500, 2)).astype(np.uint32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    with capi.World() as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.upload(bodies, sid)
+        got = w.edge_axes_separation(pairs)
+    polys = {k: ob.polytope(*v) for k, v in ORACLE_POLYS.items()}
+    frames = []
+    for b in bodies:
+        f = oracle.o_rigid_frame(C.byref(ob.Rigid.from_np(b)))
+        frames.append(f)
+    none = 0
+    for g, (i, j) in zip(got, pairs):
+        ea, eb = C.c_uint64(0), C.c_uint64(0)
+        d = oracle.o_edge_axes_separation(frames[i], frames[j], C.byref(polys[int(sid[i])]), C.byref(polys[int(sid[j])]), C.byref(ea), C.byref(eb))
+        assert bits_equal(np.array([g["separation"]]), np.array([d]))
+        want = (ea.value & 0xFFFFFFFF, eb.value & 0xFFFFFFFF)       # usize::MAX -> 0xFFFFFFFF
+        assert (int(g["edge_a"]), int(g["edge_b"])) == want
+        none += want[0] == 0xFFFFFFFF
+    assert none < len(pairs)
+    assert (got["separation"] > 0).any() and (got["separation"] < 0).any()
+    both_aligned = (pairs[:, 0] < 20) & (pairs[:, 1] < 20)          # pairs of axis-aligned bodies: most of their axes are NaN
+    assert both_aligned.sum() > 10
