@@ -34,6 +34,12 @@ struct PolytopeTables {
     const uint32_t *edge_dir_id; // [total_edges] shape-local index of every edge's direction
     uint32_t n_shapes;
     uint32_t max_verts, max_faces, max_face_verts; // over all shapes: the narrowphase launchers pick their sub-wave width by them
+    // Mixed worlds: shapes of at most 8 vertices and 8 faces are the SMALL class (0), the others class 1; a pair's class is
+    // the larger of its bodies'.  With both classes present the two-pass SAT keeps one survivor list per class and runs the
+    // small pairs in narrow groups (8 or 16 lanes, four or eight pairs per wave) instead of the widest shape's 32 or 64.
+    const uint8_t *shape_class;    // [n_shapes]
+    uint32_t two_classes;          // both classes occur
+    uint32_t small_max_face_verts; // over the small shapes
 };
 
 constexpr uint32_t kMaxManifoldPoints = 8;
@@ -76,9 +82,10 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 
 // (The pipeline's statistics -- touching pairs, contact points -- are summed by the pair solve, xpbd_contacts.hip.)
 
-// Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two uint32, zero when
-// idle; launch k appends through counters[k & 1] and its SAT kernel zeroes counters[(k + 1) & 1] for the next launch
-// (all launches of one world are stream-ordered).  `survivors`: n_pairs uint32.
+// Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two PAIRS of uint32 (one
+// counter per pair class), zero when idle; launch k appends through pair k & 1 and its consumer kernels zero pair
+// (k + 1) & 1 for the next launch (all launches of one world are stream-ordered).  `survivors`: n_pairs uint32; class 0
+// fills it from the front, class 1 from the back.
 struct SatScratch {
     uint32_t *counters;
     uint32_t *survivors;

@@ -518,52 +518,67 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(B
 }
 
 // The pre-test as a pass of its own, one LANE per pair: rejected pairs are answered, the others are appended to a
-// survivor list.  ONE atomic per 1024-pair workgroup (same-address atomics serialise at ~10-25 ns each: one per wave
-// made this pass 25 us for 50 000 pairs); the order of the list is irrelevant, results go to out[p].
+// survivor list -- with CLASSES to one list per pair class (class 0 from the front of `survivors`, class 1 from the back).
+// ONE atomic per list and 1024-pair workgroup (same-address atomics serialise at ~10-25 ns each: one per wave made this
+// pass 25 us for 50 000 pairs); the order of a list is irrelevant, results go to out[p].
 constexpr uint32_t kPretestBlock = 1024;
 
+template <bool CLASSES>
 __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                                 const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                                 ContactManifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
                                                                 uint32_t *__restrict__ survivors)
 {
-    __shared__ uint32_t wave_base[kPretestBlock / 64 + 1];
+    constexpr uint32_t NC = CLASSES ? 2 : 1;
+    __shared__ uint32_t wave_base[NC][kPretestBlock / 64 + 1];
     const uint32_t p = blockIdx.x * kPretestBlock + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool keep = false;
+    uint32_t cls = 0;
     if (p < n_pairs) {
         keep = tight_spheres_overlap(b, t, frames, pairs, p);
         if (!keep)
             out[p].n_points = 0;
+        else if (CLASSES) {
+            const uint32_t ca = t.shape_class[b.shape_id[pairs[2 * (size_t)p]]], cb = t.shape_class[b.shape_id[pairs[2 * (size_t)p + 1]]];
+            cls = ca > cb ? ca : cb;
+        }
     }
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0)
-        wave_base[wave] = (uint32_t)__popcll(mask);
+    unsigned long long mask[NC];
+#pragma unroll
+    for (uint32_t c = 0; c < NC; ++c) {
+        mask[c] = __ballot(keep && cls == c);
+        if (lane == 0)
+            wave_base[c][wave] = (uint32_t)__popcll(mask[c]);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) { // exclusive scan of the 16 wave counts, then one atomic for the whole workgroup
+    if (threadIdx.x < NC) { // exclusive scan of the 16 wave counts, then one atomic for the whole workgroup and list
+        const uint32_t c = threadIdx.x;
         uint32_t run = 0;
         for (uint32_t w = 0; w < kPretestBlock / 64; ++w) {
-            const uint32_t c = wave_base[w];
-            wave_base[w] = run;
-            run += c;
+            const uint32_t n = wave_base[c][w];
+            wave_base[c][w] = run;
+            run += n;
         }
-        const uint32_t base = run ? atomicAdd(survivor_count, run) : 0u;
-        wave_base[kPretestBlock / 64] = base;
+        wave_base[c][kPretestBlock / 64] = run ? atomicAdd(survivor_count + c, run) : 0u;
     }
     __syncthreads();
-    if (keep)
-        survivors[wave_base[kPretestBlock / 64] + wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+    if (keep) {
+        const uint32_t at = wave_base[cls][kPretestBlock / 64] + wave_base[cls][wave] + (uint32_t)__popcll(mask[cls] & ((1ull << lane) - 1ull));
+        survivors[cls ? n_pairs - 1u - at : at] = p;
+    }
 }
 
 // ... and the SAT over the survivors only, so that every group of every wave has a pair that needs it.  The grid is
 // sized for all pairs (the count lives on the device); blocks past the survivors leave at once.  Block 0 zeroes the
-// counter of the NEXT launch (the two counters alternate, as in xpbd_gjk.hip).
+// counters of the NEXT launch (the two pairs of counters alternate, as in xpbd_gjk.hip).  back_n != 0: the list that grows
+// from the back of `survivors` (entry k sits at back_n - 1 - k).
 template <uint32_t L, uint32_t V>
 __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivors(BodyArrays b, PolytopeTables t,
                                                                                    const double *__restrict__ frames,
                                                                                    const uint32_t *__restrict__ pairs,
                                                                                    const uint32_t *__restrict__ survivor_count,
-                                                                                   uint32_t *__restrict__ next_survivor_count,
-                                                                                   const uint32_t *__restrict__ survivors,
+                                                                                   uint32_t *__restrict__ next_survivor_counts,
+                                                                                   const uint32_t *__restrict__ survivors, uint32_t back_n,
                                                                                    ContactManifold *__restrict__ out)
 {
     using Lds = typename SatLds<L, V>::Record;
@@ -571,11 +586,11 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
     const uint32_t group = threadIdx.x / L, lane = threadIdx.x % L;
     const uint32_t k = blockIdx.x * SatLds<L, V>::PW + group;
     const uint32_t n = *survivor_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *next_survivor_count = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2)
+        next_survivor_counts[threadIdx.x] = 0;
     if (k >= n)
         return;
-    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[k], out, lane);
+    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -655,18 +670,24 @@ namespace {
 // most 8, one per lane) and the launch is large; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
 // 16-vertex records; anything larger gets a whole wave.
 template <class Launch>
-void for_shape_class(const PolytopeTables &t, uint32_t n_pairs, Launch launch)
+void for_shape_maxima(uint32_t max_verts, uint32_t max_faces, uint32_t max_face_verts, uint32_t n_pairs, Launch launch)
 {
     // 8 lanes per pair halve the instructions per pair of the clipping half of the SAT (208 -> 148 us on 245 760 box
     // pairs) but lengthen the chain of a wave: only when there are enough pairs to fill the GPU with 8-pair waves
-    if (t.max_verts <= 8 && t.max_faces <= 8 && t.max_face_verts <= 4 && n_pairs >= kWidePairCount)
+    if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && n_pairs >= kWidePairCount)
         launch(std::integral_constant<uint32_t, XPBD_SAT_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
-    else if (t.max_verts <= 8 && t.max_faces <= 8)
+    else if (max_verts <= 8 && max_faces <= 8)
         launch(std::integral_constant<uint32_t, XPBD_SAT_SMALL_LANES>{}, std::integral_constant<uint32_t, 8>{});
-    else if (t.max_verts <= 16)
+    else if (max_verts <= 16)
         launch(std::integral_constant<uint32_t, XPBD_SAT_MID_LANES>{}, std::integral_constant<uint32_t, 16>{});
     else
         launch(std::integral_constant<uint32_t, 64>{}, std::integral_constant<uint32_t, kMaxV>{});
+}
+
+template <class Launch>
+void for_shape_class(const PolytopeTables &t, uint32_t n_pairs, Launch launch)
+{
+    for_shape_maxima(t.max_verts, t.max_faces, t.max_face_verts, n_pairs, launch);
 }
 } // namespace
 
@@ -694,10 +715,10 @@ hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, con
                                uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
                                hipStream_t stream)
 {
-    *count = list.counters + (list.calls & 1u);
-    *next_count = list.counters + ((list.calls + 1u) & 1u);
+    *count = list.counters + 2u * (list.calls & 1u);
+    *next_count = list.counters + 2u * ((list.calls + 1u) & 1u);
     ++list.calls;
-    hipLaunchKernelGGL(k_pair_pretest, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
+    hipLaunchKernelGGL(k_pair_pretest<false>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
                        pairs, n_pairs, out, *count, list.survivors);
     return hipGetLastError();
 }
@@ -707,13 +728,32 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
 {
     if (n_pairs == 0)
         return hipSuccess;
+    if (list && t.two_classes) {
+        // pre-test pass into one survivor list per pair class, then the small pairs in narrow groups and the others in the
+        // widest shape's: every wave is full of pairs of its own kind
+        uint32_t *count = list->counters + 2u * (list->calls & 1u), *next = list->counters + 2u * ((list->calls + 1u) & 1u);
+        ++list->calls;
+        hipLaunchKernelGGL(k_pair_pretest<true>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
+                           frames, pairs, n_pairs, out, count, list->survivors);
+        for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, [&](auto lanes, auto verts) {
+            constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
+            hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,
+                               next, list->survivors, 0u, out);
+        });
+        for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
+            constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
+            hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs,
+                               count + 1, next, list->survivors, n_pairs, out);
+        });
+        return hipGetLastError();
+    }
     for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
         constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
         const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
         if (list) { // pre-test pass, then the SAT over the survivors
             uint32_t *count = nullptr, *next = nullptr;
             (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, out, *list, &count, &next, stream);
-            hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, out);
+            hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, 0u, out);
         } else {
             hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         }

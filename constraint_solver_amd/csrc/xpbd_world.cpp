@@ -120,7 +120,8 @@ struct xpbd_world {
 
     // extension: polytope topology for the body-body narrowphase
     DeviceBuffer planes, centroids, shape_desc, face_start, face_verts, edges, pair_buf, manifold_buf;
-    DeviceBuffer shape_radii, edge_dirs, edge_dir_id;
+    DeviceBuffer shape_radii, edge_dirs, edge_dir_id, shape_class;
+    uint32_t two_classes = 0, small_max_face_verts = 0;
     bool has_topology = false;
     uint32_t max_verts = 0, max_faces = 0, max_face_verts = 0;
     xpbd::PolytopeTables tables() const
@@ -128,7 +129,8 @@ struct xpbd_world {
         return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
                                     shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
                                     face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(),
-                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, max_verts, max_faces, max_face_verts};
+                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, max_verts, max_faces, max_face_verts,
+                                    shape_class.as<uint8_t>(), two_classes, small_max_face_verts};
     }
 
     // extension: contact pipeline (XPBD_MODE_CONTACTS)
@@ -293,14 +295,16 @@ int build_neighbours(xpbd_world *w, double dt)
         const unsigned long long examined = w->stats_pair_substeps - w->stats_pair_substeps_seen;
         if (w->sat_schedule != XPBD_SAT_SCHEDULE_AUTO)
             w->sat_two_pass = w->sat_schedule == XPBD_SAT_SCHEDULE_TWO_PASS;
+        else if (w->two_classes && w->narrowphase == XPBD_NARROWPHASE_SAT)
+            w->sat_two_pass = true; // small and large shapes: the two-pass form sorts the pairs by class (xpbd_pairs.h)
         else if (examined)
             w->sat_two_pass = touching * 4 < examined;
         w->stats_touching_seen = stats_now[0];
         w->stats_pair_substeps_seen = w->stats_pair_substeps;
     }
     if (!w->sat_counters.ptr) {
-        XPBD_HIP_TRY(w->sat_counters.reserve(8));
-        XPBD_HIP_TRY(hipMemsetAsync(w->sat_counters.ptr, 0, 8, w->stream));
+        XPBD_HIP_TRY(w->sat_counters.reserve(16));
+        XPBD_HIP_TRY(hipMemsetAsync(w->sat_counters.ptr, 0, 16, w->stream));
         w->sat_scratch.calls = 0;
     }
     XPBD_HIP_TRY(w->sat_survivors.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 4));
@@ -464,7 +468,7 @@ void xpbd_world_destroy(xpbd_world *w)
     for (DeviceBuffer *b : {&w->dyn, &w->stat, &w->shape_id, &w->aos_staging, &w->last_mask, &w->trace,
                             &w->block_counts, &w->contacts, &w->shape_verts, &w->shape_offsets, &w->planes,
                             &w->centroids, &w->shape_desc, &w->face_start, &w->face_verts, &w->edges, &w->pair_buf,
-                            &w->manifold_buf, &w->shape_radii, &w->edge_dirs, &w->edge_dir_id, &w->dyn_alt, &w->cb_centers, &w->cb_radius, &w->cb_cell,
+                            &w->manifold_buf, &w->shape_radii, &w->edge_dirs, &w->edge_dir_id, &w->shape_class, &w->dyn_alt, &w->cb_centers, &w->cb_radius, &w->cb_cell,
                             &w->cb_key, &w->cb_maxr, &w->cb_bucket_start, &w->cb_bucket_cursor, &w->cb_items,
                             &w->cb_nbr_off, &w->cb_pair_first, &w->cb_upper_start, &w->cb_nbr, &w->cb_nbr_pair,
                             &w->cb_pairs, &w->cb_rec, &w->cb_stat_rec, &w->cb_manifolds,
@@ -619,15 +623,24 @@ int xpbd_world_set_polytopes(xpbd_world *w, const xpbd_polytope *shapes, uint32_
     XPBD_HIP_TRY(upload(w->edge_dirs, dirs.data(), dirs.size() * 8));
     XPBD_HIP_TRY(upload(w->edge_dir_id, dir_id.data(), dir_id.size() * 4));
     w->has_topology = true;
-    uint32_t max_verts = 0, max_faces = 0, max_face_verts = 0;
+    uint32_t max_verts = 0, max_faces = 0, max_face_verts = 0, small_max_face_verts = 0, n_small = 0;
+    std::vector<uint8_t> shape_class(n_shapes, 0);
     for (uint32_t k = 0; k < n_shapes; ++k) {
         max_verts = shapes[k].n_vertices > max_verts ? shapes[k].n_vertices : max_verts;
         max_faces = shapes[k].n_faces > max_faces ? shapes[k].n_faces : max_faces;
+        const bool small = shapes[k].n_vertices <= 8 && shapes[k].n_faces <= 8;
+        shape_class[k] = small ? 0 : 1;
+        n_small += small;
         for (uint32_t f = 0; f < shapes[k].n_faces; ++f) {
             const uint32_t nfv = shapes[k].face_offsets[f + 1] - shapes[k].face_offsets[f];
             max_face_verts = nfv > max_face_verts ? nfv : max_face_verts;
+            if (small)
+                small_max_face_verts = nfv > small_max_face_verts ? nfv : small_max_face_verts;
         }
     }
+    XPBD_HIP_TRY(upload(w->shape_class, shape_class.data(), shape_class.size()));
+    w->two_classes = (n_small != 0 && n_small != n_shapes) ? 1u : 0u;
+    w->small_max_face_verts = small_max_face_verts;
     w->max_verts = max_verts;
     w->max_faces = max_faces;
     w->max_face_verts = max_face_verts;
