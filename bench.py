@@ -325,10 +325,12 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
     for _ in range(preroll + warmup):
         world.step(FRAME_TIME, args.substeps)
     world.contact_stats()
+    plans_before = world.halo_stats()["plans"]
     wall, _ = timed_frames(lambda: world.step(FRAME_TIME, args.substeps), torch.cuda.current_stream(), steps)
     result = None
     if rank == 0:
         halo = world.halo_stats()
+        halo["plans_during_the_timed_frames"] = halo["plans"] - plans_before
         pairs, touching, points = world.contact_stats()            # of this process's shards (owned + ghost bodies)
         n_sub = max(steps * args.substeps, 1)
         result = {

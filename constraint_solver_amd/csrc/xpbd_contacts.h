@@ -58,6 +58,19 @@ struct ContactBuffers {
     const uint32_t *joint_list;  // [2 * n_joints]
 };
 
+// Which bodies a per-body kernel of the pipeline works on.  Default: all of them.  The multi-GPU world (xpbd_multi.cpp) runs
+// the BOUNDARY bodies first, with their end-of-substep state exported straight into the halo send buffer, starts the
+// exchange, runs the interior bodies meanwhile (`skip` marks boundary and ghost bodies), and finally gives the ghosts their
+// owners' state from the gathered buffer.
+struct BodySubset {
+    const uint32_t *list = nullptr;        // NULL: bodies 0..n (minus `skip`); else the bodies list[0..count)
+    uint32_t count = 0;
+    const uint8_t *skip = nullptr;         // with list == NULL: bodies with skip[i] != 0 are left out
+    double *export_rows = nullptr;         // with list (pair-solve kernels): the end-of-substep state of list[k] -> row k (13 doubles)
+    const double *import_buf = nullptr;    // with list (integrate kernel): the state of list[k] comes from row import_rows[k]
+    const uint32_t *import_rows = nullptr;
+};
+
 // ---- broadphase (once per step call) -------------------------------------------------------------
 hipError_t launch_bounds_and_cells(const BodyArrays &b, const PolytopeTables &t, const double *shape_radius,
                                    double dt, double pad, const ContactBuffers &c, hipStream_t stream);
@@ -69,7 +82,8 @@ hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, h
 // ---- per substep -----------------------------------------------------------------------------------
 // integrate + ground contacts (sequential per body): reads b.dyn, writes the body's record (frames, pose') into c.rec
 hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
-                                   uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream);
+                                   uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream,
+                                   const BodySubset &subset = BodySubset());
 // SAT of every neighbour pair on the post-integrate frames
 // (list: NULL = pre-test inside the SAT kernel, else the two-pass form of launch_sat_pairs)
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
@@ -77,7 +91,7 @@ hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t
 // Jacobi pair solve + derive: reads the records, writes all 13 dynamic fields to dyn_out (b.dyn itself is fine: nobody
 // reads another body's SoA state here)
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
-                                    hipStream_t stream);
+                                    hipStream_t stream, const BodySubset &subset = BodySubset());
 
 // launch_pair_solve_derive of this substep and launch_integrate_ground of the next one in a single kernel: the next
 // substep's records go to next_rec (a second set: the records in `c` are still being read by the other bodies); the SoA
@@ -85,7 +99,7 @@ hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double
 // writes it).
 hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
                                               double *next_rec, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
-                                              hipStream_t stream);
+                                              hipStream_t stream, const BodySubset &subset = BodySubset());
 
 // Rigid::frame() of all bodies from the SoA state into the post-integrate frame of their records (all the diagnostic
 // narrowphase entry points need); and the StatRecords from the SoA static fields (after an upload).

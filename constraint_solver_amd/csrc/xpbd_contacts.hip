@@ -485,11 +485,40 @@ __global__ void k_neighbour_pair_index(BodyArrays b, ContactBuffers c)
     }
 }
 
+// Body of work item `slot` under a BodySubset (false: nothing to do).
+__device__ __forceinline__ bool subset_body(const BodySubset &ss, uint32_t n, uint32_t slot, uint32_t &i)
+{
+    if (ss.list) {
+        if (slot >= ss.count)
+            return false;
+        i = ss.list[slot];
+        return true;
+    }
+    i = slot;
+    return slot < n && !(ss.skip && ss.skip[slot]);
+}
+
+// The 13 dynamic doubles of a body as one body-major row (halo buffers): position, rotation s x y z, velocity, angular velocity.
+__device__ __forceinline__ void store_row(double *__restrict__ rows, uint32_t r, const BodyDynamic &d)
+{
+    double *o = rows + (size_t)r * kDynFields;
+    o[0] = d.pos.x, o[1] = d.pos.y, o[2] = d.pos.z;
+    o[3] = d.rot.s, o[4] = d.rot.x, o[5] = d.rot.y, o[6] = d.rot.z;
+    o[7] = d.vel.x, o[8] = d.vel.y, o[9] = d.vel.z;
+    o[10] = d.ang.x, o[11] = d.ang.y, o[12] = d.ang.z;
+}
+
+__device__ __forceinline__ BodyDynamic load_row(const double *__restrict__ rows, uint32_t r)
+{
+    const double *o = rows + (size_t)r * kDynFields;
+    return BodyDynamic{Vec3{o[0], o[1], o[2]}, Quat{o[3], o[4], o[5], o[6]}, Vec3{o[7], o[8], o[9]}, Vec3{o[10], o[11], o[12]}};
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Per substep, per body: integrate, remember the frames, ground contacts (reference path).
 // ---------------------------------------------------------------------------------------------------
 template <bool TRACE>
-__global__ void __launch_bounds__(kBlock) k_integrate_ground(BodyArrays b, ShapeTable shapes, double h, ContactBuffers c,
+__global__ void __launch_bounds__(kBlock) k_integrate_ground(BodyArrays b, ShapeTable shapes, double h, ContactBuffers c, BodySubset subset,
                                                              uint32_t *__restrict__ last_mask,
                                                              uint32_t *__restrict__ trace_masks, uint32_t trace_row)
 {
@@ -501,12 +530,14 @@ __global__ void __launch_bounds__(kBlock) k_integrate_ground(BodyArrays b, Shape
         lds_off[k] = shapes.offsets[k];
     __syncthreads();
 
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n)
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i;
+    if (!subset_body(subset, b.n, slot, i))
         return;
     const uint32_t st = b.stride;
     const BodyStatic s = load_static(b, i);
-    BodyDynamic d = load_dynamic(b.dyn, st, i);
+    // (a ghost body starts the substep from its owner's end-of-substep state, straight from the gathered halo buffer)
+    BodyDynamic d = subset.import_buf ? load_row(subset.import_buf, subset.import_rows[slot]) : load_dynamic(b.dyn, st, i);
     const uint32_t sid = b.shape_id[i];
     const uint32_t v0 = lds_off[sid];
     const double compliance = 1e-6 / (h * h);
@@ -792,16 +823,19 @@ __device__ __forceinline__ void block_add_stats(uint32_t touching, uint32_t poin
 
 template <uint32_t G>
 __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_derive(BodyArrays b, double *__restrict__ dyn_out, double h,
-                                                                                        ContactBuffers c)
+                                                                                        ContactBuffers c, BodySubset subset)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, i = gid / G, sub = gid % G;
-    uint32_t touching = 0, points = 0;
-    if (i < b.n) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, slot = gid / G, sub = gid % G;
+    uint32_t touching = 0, points = 0, i;
+    if (subset_body(subset, b.n, slot, i)) {
         Vec3 past_pos;
         const PairBody self = load_pair_body(c, i, &past_pos);
         const BodyDynamic d = pair_solve_derive_body<G>(b, c, i, h, self, past_pos, sub, touching, points);
-        if (sub == 0)
+        if (sub == 0) {
             store_dynamic(dyn_out, b.stride, i, d);
+            if (subset.export_rows)
+                store_row(subset.export_rows, slot, d);
+        }
     }
     block_add_stats(sub == 0 ? touching : 0u, sub == 0 ? points : 0u, c.stats);
 }
@@ -816,8 +850,8 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
 // lanes and lane 0 stores.)
 template <bool TRACE, uint32_t G>
 __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solve_integrate_ground(
-    BodyArrays b, ShapeTable shapes, double h, ContactBuffers c, double *__restrict__ next_rec, uint32_t *__restrict__ last_mask,
-    uint32_t *__restrict__ trace_masks, uint32_t trace_row)
+    BodyArrays b, ShapeTable shapes, double h, ContactBuffers c, BodySubset subset, double *__restrict__ next_rec,
+    uint32_t *__restrict__ last_mask, uint32_t *__restrict__ trace_masks, uint32_t trace_row)
 {
     extern __shared__ double lds[]; // shape vertex tables, as in k_integrate_ground
     uint32_t *lds_off = reinterpret_cast<uint32_t *>(lds + 3 * shapes.total_verts);
@@ -827,9 +861,9 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         lds_off[k] = shapes.offsets[k];
     __syncthreads();
 
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, i = gid / G, sub = gid % G;
-    uint32_t touching = 0, points = 0;
-    if (i < b.n) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, slot = gid / G, sub = gid % G;
+    uint32_t touching = 0, points = 0, i;
+    if (subset_body(subset, b.n, slot, i)) {
         const uint32_t st = b.stride;
         BodyDynamic d;
         BodyStatic s;
@@ -839,6 +873,8 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
             d = pair_solve_derive_body<G>(b, c, i, h, self, past_pos, sub, touching, points);
             s = static_of(b, i, self.inv_mass, self.inv_inertia, self.com);
         }
+        if (subset.export_rows && sub == 0)
+            store_row(subset.export_rows, slot, d); // the end-of-substep state, before the next substep's integration
         const uint32_t sid = b.shape_id[i];
         const uint32_t v0 = lds_off[sid];
         const double compliance = 1e-6 / (h * h);
@@ -985,16 +1021,18 @@ hipError_t launch_neighbour_fill(const BodyArrays &b, const ContactBuffers &c, h
 }
 
 hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
-                                   uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream)
+                                   uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream,
+                                   const BodySubset &subset)
 {
-    if (b.n == 0)
+    const uint32_t items = subset.list ? subset.count : b.n;
+    if (items == 0)
         return hipSuccess;
     const size_t lds_bytes = (size_t)s.total_verts * 3 * sizeof(double) + (size_t)(s.n_shapes + 1) * sizeof(uint32_t);
     if (trace_masks)
-        hipLaunchKernelGGL(k_integrate_ground<true>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, h, c,
+        hipLaunchKernelGGL(k_integrate_ground<true>, dim3(blocks_for(items)), dim3(kBlock), lds_bytes, stream, b, s, h, c, subset,
                            last_mask, trace_masks, trace_row);
     else
-        hipLaunchKernelGGL(k_integrate_ground<false>, dim3(blocks_for(b.n)), dim3(kBlock), lds_bytes, stream, b, s, h, c,
+        hipLaunchKernelGGL(k_integrate_ground<false>, dim3(blocks_for(items)), dim3(kBlock), lds_bytes, stream, b, s, h, c, subset,
                            last_mask, trace_masks, trace_row);
     return hipGetLastError();
 }
@@ -1006,29 +1044,31 @@ hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,
-                                    hipStream_t stream)
+                                    hipStream_t stream, const BodySubset &subset)
 {
-    if (b.n == 0)
+    const uint32_t items = subset.list ? subset.count : b.n;
+    if (items == 0)
         return hipSuccess;
     if (b.n <= kSmallWorld)
-        hipLaunchKernelGGL(k_pair_solve_derive<kMaxManifoldPoints>, dim3(blocks_for(b.n * kMaxManifoldPoints)), dim3(kBlock), 0, stream, b,
-                           dyn_out, h, c);
+        hipLaunchKernelGGL(k_pair_solve_derive<kMaxManifoldPoints>, dim3(blocks_for(items * kMaxManifoldPoints)), dim3(kBlock), 0, stream, b,
+                           dyn_out, h, c, subset);
     else
-        hipLaunchKernelGGL(k_pair_solve_derive<1>, dim3(blocks_for(b.n)), dim3(kBlock), 0, stream, b, dyn_out, h, c);
+        hipLaunchKernelGGL(k_pair_solve_derive<1>, dim3(blocks_for(items)), dim3(kBlock), 0, stream, b, dyn_out, h, c, subset);
     return hipGetLastError();
 }
 
 hipError_t launch_pair_solve_integrate_ground(const BodyArrays &b, const ShapeTable &s, double h, const ContactBuffers &c,
                                               double *next_rec, uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row,
-                                              hipStream_t stream)
+                                              hipStream_t stream, const BodySubset &subset)
 {
-    if (b.n == 0)
+    const uint32_t items = subset.list ? subset.count : b.n;
+    if (items == 0)
         return hipSuccess;
     const size_t lds_bytes = (size_t)s.total_verts * 3 * sizeof(double) + (size_t)(s.n_shapes + 1) * sizeof(uint32_t);
     auto launch = [&](auto trace, auto lanes) {
         constexpr uint32_t G = decltype(lanes)::value;
-        hipLaunchKernelGGL((k_pair_solve_integrate_ground<decltype(trace)::value, G>), dim3(blocks_for(b.n * G)), dim3(kBlock), lds_bytes,
-                           stream, b, s, h, c, next_rec, last_mask, trace_masks, trace_row);
+        hipLaunchKernelGGL((k_pair_solve_integrate_ground<decltype(trace)::value, G>), dim3(blocks_for(items * G)), dim3(kBlock), lds_bytes,
+                           stream, b, s, h, c, subset, next_rec, last_mask, trace_masks, trace_row);
     };
     using Wide = std::integral_constant<uint32_t, kMaxManifoldPoints>;
     using One = std::integral_constant<uint32_t, 1>;

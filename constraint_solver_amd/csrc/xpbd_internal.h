@@ -8,4 +8,35 @@ namespace xpbd {
 // Records the thread's last error message (xpbd_last_error) and returns `code`.
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// ---- one frame of a shard of the multi-GPU world (xpbd_multi.cpp), split at the halo exchange ---------------------------
+// All device pointers; slots are local body indices of the shard's world.
+struct HaloLists {
+    const uint32_t *boundary;   // owned bodies that other ranks mirror (ascending)
+    uint32_t n_boundary;
+    const uint32_t *ghosts;     // local copies of remote bodies (ascending)
+    const uint32_t *ghost_rows; // their rows in the gathered buffer
+    uint32_t n_ghosts;
+    const uint8_t *skip;        // [n] 1 for boundary and ghost bodies: what the interior launch leaves out (NULL: none)
+    double *send;               // n_boundary rows of 13 doubles: this shard's contribution to the all-gather
+    const double *recv;         // the gathered buffer
+};
+
+} // namespace xpbd
+
+struct xpbd_world;
+
+namespace xpbd {
+// frame:   halo_frame_begin; substeps x { halo_substep_boundary; <all-gather send -> recv, overlapping:> halo_substep_interior;
+//          <wait for the gather> halo_substep_ghosts }
+// begin:    the broadphase of the frame and the integrate + ground stage of substep 0 for every local body
+// boundary: the narrowphase of substep k, then the pair solve (+ the integrate + ground stage of substep k + 1 unless `last`)
+//           of the BOUNDARY bodies, whose end-of-substep state goes straight into `send`
+// interior: the same for the owned bodies nobody mirrors
+// ghosts:   the ghosts take their owners' end-of-substep state from `recv` (and run their own integrate + ground stage of
+//           substep k + 1 unless `last`)
+// Same arithmetic per body as xpbd_world_step, so the same bits.
+int halo_frame_begin(xpbd_world *w, double dt, double h);
+int halo_substep_boundary(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
+int halo_substep_interior(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
+int halo_substep_ghosts(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
 } // namespace xpbd

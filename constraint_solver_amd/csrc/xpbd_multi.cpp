@@ -194,16 +194,18 @@ struct Shard {
     uint32_t rank = 0;
     Range own{0, 0};
     xpbd_world *world = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the shard's world stream: every kernel of the shard
+    hipStream_t comm_stream = nullptr; // the per-substep halo all-gather, overlapping the interior bodies' kernels
     ncclComm_t comm = nullptr;
-    hipEvent_t ev_send = nullptr, ev_recv = nullptr;
+    hipEvent_t ev_send = nullptr, ev_recv = nullptr; // in-process transport
+    hipEvent_t ev_ready = nullptr, ev_gathered = nullptr; // world stream -> communication stream -> world stream
     // the owned bodies as last uploaded / re-planned (host): kRigid doubles each, shape ids
     std::vector<double> owned;
     std::vector<uint32_t> owned_sid;
     // plan
     std::vector<uint32_t> local_ids, ghosts, boundary;
     uint32_t own_slot0 = 0; // local slot of the first owned body (the owned bodies are contiguous in the local order)
-    DevBuf boundary_slots, ghost_slots, ghost_rows, owned_slots, send, recv, snapshot, disp, disp_all, stage_send, stage_recv;
+    DevBuf boundary_slots, ghost_slots, ghost_rows, owned_slots, skip_flags, send, recv, snapshot, disp, disp_all, stage_send, stage_recv;
     double *disp_host = nullptr; // pinned, n_ranks doubles
 };
 
@@ -239,9 +241,12 @@ int nccl_fail(const xpbd_multi_world *mw, ncclResult_t r, const char *what)
 
 // One all-gather over all ranks: every local shard contributes `bytes` from its `send` and receives n_ranks x bytes into its
 // `recv` (device pointers, picked per shard by the callbacks), ordered on the shards' streams.
+// `on_comm_stream`: enqueue on the shards' communication streams (the caller orders them against the world streams with
+// events) instead of the world streams.
 template <class Send, class Recv>
-int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv recv_of)
+int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv recv_of, bool on_comm_stream = false)
 {
+    auto stream_of = [on_comm_stream](Shard &s) { return on_comm_stream ? s.comm_stream : s.stream; };
     if (mw->transport == XPBD_TRANSPORT_RCCL) {
         // RCCL reads the thread's last HIP error after its own calls: a stale, harmless one left by somebody else in the
         // process (hipErrorNotReady from an event query, say) would be reported as "unhandled cuda error"
@@ -251,7 +256,7 @@ int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv rec
             return nccl_fail(mw, r, "ncclGroupStart");
         for (Shard &s : mw->shards) {
             MW_TRY(bind(s));
-            r = mw->rccl->AllGather(send_of(s), recv_of(s), bytes, ncclChar, s.comm, s.stream);
+            r = mw->rccl->AllGather(send_of(s), recv_of(s), bytes, ncclChar, s.comm, stream_of(s));
             if (r != ncclSuccess) {
                 (void)mw->rccl->GroupEnd();
                 return nccl_fail(mw, r, "ncclAllGather");
@@ -265,22 +270,22 @@ int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv rec
     // XPBD_TRANSPORT_LOCAL: every rank lives in this process; peer copies ordered by events
     for (Shard &p : mw->shards) {
         MW_TRY(bind(p));
-        MW_HIP_TRY(hipEventRecord(p.ev_send, p.stream));
+        MW_HIP_TRY(hipEventRecord(p.ev_send, stream_of(p)));
     }
     for (Shard &r : mw->shards) {
         MW_TRY(bind(r));
         for (Shard &p : mw->shards) {
             if (&p != &r)
-                MW_HIP_TRY(hipStreamWaitEvent(r.stream, p.ev_send, 0));
-            MW_HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv_of(r)) + (size_t)p.rank * bytes, send_of(p), bytes, hipMemcpyDefault, r.stream));
+                MW_HIP_TRY(hipStreamWaitEvent(stream_of(r), p.ev_send, 0));
+            MW_HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv_of(r)) + (size_t)p.rank * bytes, send_of(p), bytes, hipMemcpyDefault, stream_of(r)));
         }
-        MW_HIP_TRY(hipEventRecord(r.ev_recv, r.stream));
+        MW_HIP_TRY(hipEventRecord(r.ev_recv, stream_of(r)));
     }
     for (Shard &p : mw->shards) { // nobody overwrites its send buffer before every peer has read it
         MW_TRY(bind(p));
         for (Shard &r : mw->shards)
             if (&p != &r)
-                MW_HIP_TRY(hipStreamWaitEvent(p.stream, r.ev_recv, 0));
+                MW_HIP_TRY(hipStreamWaitEvent(stream_of(p), r.ev_recv, 0));
     }
     return XPBD_OK;
 }
@@ -492,6 +497,12 @@ int make_plan(xpbd_multi_world *mw)
         MW_TRY(upload_vector(s.ghost_slots, ghost_slots, s.stream));
         MW_TRY(upload_vector(s.ghost_rows, ghost_rows, s.stream));
         MW_TRY(upload_vector(s.owned_slots, owned_slots, s.stream));
+        std::vector<uint8_t> skip(n_loc, 0); // what the interior launch leaves out: boundary bodies (done first) and ghosts (done last)
+        for (uint32_t q : boundary_slots)
+            skip[q] = 1;
+        for (uint32_t q : ghost_slots)
+            skip[q] = 1;
+        MW_TRY(upload_vector(s.skip_flags, skip, s.stream));
         MW_HIP_TRY(s.send.reserve((size_t)rows * kDyn * 8));
         MW_HIP_TRY(s.recv.reserve((size_t)w * rows * kDyn * 8));
         MW_HIP_TRY(hipMemsetAsync(s.send.ptr, 0, (size_t)rows * kDyn * 8, s.stream));
@@ -556,12 +567,18 @@ void destroy(xpbd_multi_world *mw)
             (void)hipStreamSynchronize(s.stream);
         if (s.comm && mw->rccl)
             (void)mw->rccl->CommDestroy(s.comm);
-        for (DevBuf *b : {&s.boundary_slots, &s.ghost_slots, &s.ghost_rows, &s.owned_slots, &s.send, &s.recv, &s.snapshot, &s.disp, &s.disp_all, &s.stage_send, &s.stage_recv})
+        for (DevBuf *b : {&s.boundary_slots, &s.ghost_slots, &s.ghost_rows, &s.owned_slots, &s.skip_flags, &s.send, &s.recv, &s.snapshot, &s.disp, &s.disp_all, &s.stage_send, &s.stage_recv})
             b->release();
         if (s.disp_host)
             (void)hipHostFree(s.disp_host);
+        if (s.comm_stream)
+            (void)hipStreamDestroy(s.comm_stream);
         if (s.ev_send)
             (void)hipEventDestroy(s.ev_send);
+        if (s.ev_ready)
+            (void)hipEventDestroy(s.ev_ready);
+        if (s.ev_gathered)
+            (void)hipEventDestroy(s.ev_gathered);
         if (s.ev_recv)
             (void)hipEventDestroy(s.ev_recv);
         xpbd_world_destroy(s.world);
@@ -668,6 +685,9 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
         hipError_t e = hipSetDevice(s.device);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_send, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_recv, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_gathered, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.disp_host), (size_t)cfg->n_ranks * 8, hipHostMallocDefault);
         if (e != hipSuccess)
             return bail(set_error(XPBD_E_HIP, "xpbd_multi_world_create: %s", hipGetErrorString(e)));
@@ -796,24 +816,49 @@ int xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps)
     }
     const double h = dt / (double)substeps; // src/solver.rs:4
     for (Shard &s : mw->shards)
-        if (int rc = xpbd_world_contacts_begin(s.world, dt))
+        if (int rc = xpbd::halo_frame_begin(s.world, dt, h))
             return rc;
-    const uint32_t rows = mw->rows_per_rank();
-    const size_t bytes = (size_t)rows * kDyn * 8;
+    const size_t bytes = (size_t)mw->rows_per_rank() * kDyn * 8;
+    auto lists_of = [](Shard &s) {
+        return xpbd::HaloLists{s.boundary_slots.as<uint32_t>(), (uint32_t)s.boundary.size(), s.ghost_slots.as<uint32_t>(), s.ghost_rows.as<uint32_t>(),
+                               (uint32_t)s.ghosts.size(), s.skip_flags.as<uint8_t>(), s.send.as<double>(), s.recv.as<double>()};
+    };
     for (uint32_t k = 0; k < substeps; ++k) {
-        for (Shard &s : mw->shards)
-            if (int rc = xpbd_world_contacts_substep(s.world, h))
+        const bool last = k + 1 == substeps;
+        // 1. the narrowphase, then the boundary bodies: their end-of-substep state lands in the send buffer
+        for (Shard &s : mw->shards) {
+            if (int rc = xpbd::halo_substep_boundary(s.world, h, k, last, lists_of(s)))
                 return rc;
-        if (mw->n_ranks == 1)
-            continue;
+            if (mw->n_ranks > 1) {
+                MW_TRY(bind(s));
+                MW_HIP_TRY(hipEventRecord(s.ev_ready, s.stream));
+                MW_HIP_TRY(hipStreamWaitEvent(s.comm_stream, s.ev_ready, 0));
+            }
+        }
+        // 2. ONE all-gather per substep on the communication streams ...
+        if (mw->n_ranks > 1) {
+            MW_TRY(all_gather_device(mw, bytes, [](Shard &s) { return s.send.ptr; }, [](Shard &s) { return s.recv.ptr; }, true));
+            for (Shard &s : mw->shards) {
+                MW_TRY(bind(s));
+                MW_HIP_TRY(hipEventRecord(s.ev_gathered, s.comm_stream));
+            }
+        }
+        // 3. ... while the interior bodies (nobody mirrors them) run on the world streams
         for (Shard &s : mw->shards)
-            if (int rc = xpbd_world_export_dynamic(s.world, s.boundary_slots.as<uint32_t>(), (uint32_t)s.boundary.size(), s.send.as<double>()))
+            if (int rc = xpbd::halo_substep_interior(s.world, h, k, last, lists_of(s)))
                 return rc;
-        MW_TRY(all_gather_device(mw, bytes, [](Shard &s) { return s.send.ptr; }, [](Shard &s) { return s.recv.ptr; }));
-        for (Shard &s : mw->shards)
-            if (int rc = xpbd_world_import_dynamic_rows(s.world, s.ghost_slots.as<uint32_t>(), s.ghost_rows.as<uint32_t>(), (uint32_t)s.ghosts.size(),
-                                                        s.recv.as<double>()))
-                return rc;
+        // 4. the ghosts take their owners' state from the gathered buffer
+        if (mw->n_ranks > 1)
+            for (Shard &s : mw->shards) {
+                MW_TRY(bind(s));
+                MW_HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
+                if (int rc = xpbd::halo_substep_ghosts(s.world, h, k, last, lists_of(s)))
+                    return rc;
+                // the next substep's boundary launch rewrites the send buffer: not before this exchange has read it
+                // (the communication stream is in order, so waiting for ev_gathered above covers the own copy; the peers'
+                // reads of OUR buffer are ordered by the transport: RCCL completes the collective, the in-process
+                // transport makes the communication streams wait for every peer's ev_recv)
+            }
     }
     return XPBD_OK;
 }

@@ -382,6 +382,88 @@ int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_
 
 } // namespace
 
+// ---- the frame of a multi-GPU shard, split at the halo exchange (xpbd_internal.h) -------------------------------------------
+namespace xpbd {
+
+int halo_frame_begin(xpbd_world *w, double dt, double h)
+{
+    if (!w || w->mode != XPBD_MODE_CONTACTS || !w->has_topology)
+        return fail(XPBD_E_INVALID, "halo_frame_begin: needs XPBD_MODE_CONTACTS and xpbd_world_set_polytopes");
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    if (int rc = build_neighbours(w, dt))
+        return rc;
+    XPBD_HIP_TRY(launch_integrate_ground(w->arrays(), w->shapes(), h, w->contact_buffers(0), w->last_mask.as<uint32_t>(), nullptr, 0, w->stream));
+    w->stepped = true;
+    return XPBD_OK;
+}
+
+namespace {
+// pair solve (+ next substep's integrate + ground unless `last`) of the bodies of `subset`
+int halo_pair_solve(xpbd_world *w, double h, uint32_t k, bool last, const BodySubset &subset)
+{
+    const BodyArrays b = w->arrays();
+    const ContactBuffers c = w->contact_buffers(k & 1u);
+    if (last)
+        XPBD_HIP_TRY(launch_pair_solve_derive(b, b.dyn, h, c, w->stream, subset));
+    else
+        XPBD_HIP_TRY(launch_pair_solve_integrate_ground(b, w->shapes(), h, c, w->contact_buffers((k + 1u) & 1u).rec, w->last_mask.as<uint32_t>(),
+                                                        nullptr, k + 1, w->stream, subset));
+    return XPBD_OK;
+}
+} // namespace
+
+int halo_substep_boundary(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l)
+{
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    if (int rc = narrowphase_contacts(w, w->arrays(), w->contact_buffers(k & 1u)))
+        return rc;
+    BodySubset subset;
+    subset.list = l.boundary;
+    subset.count = l.n_boundary;
+    subset.export_rows = l.send;
+    return halo_pair_solve(w, h, k, last, subset);
+}
+
+int halo_substep_interior(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l)
+{
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    BodySubset subset;
+    subset.skip = l.skip;
+    return halo_pair_solve(w, h, k, last, subset);
+}
+
+int halo_substep_ghosts(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l)
+{
+    if (w->n == 0 || l.n_ghosts == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    const BodyArrays b = w->arrays();
+    if (last) {
+        XPBD_HIP_TRY(launch_import_dynamic(b, l.ghosts, l.ghost_rows, l.n_ghosts, l.recv, w->stream));
+        return XPBD_OK;
+    }
+    BodySubset subset;
+    subset.list = l.ghosts;
+    subset.count = l.n_ghosts;
+    subset.import_buf = l.recv;
+    subset.import_rows = l.ghost_rows;
+    XPBD_HIP_TRY(launch_integrate_ground(b, w->shapes(), h, w->contact_buffers((k + 1u) & 1u), w->last_mask.as<uint32_t>(), nullptr, k + 1, w->stream,
+                                         subset));
+    return XPBD_OK;
+}
+
+} // namespace xpbd
+
 extern "C" {
 
 uint32_t xpbd_abi_version(void) { return XPBD_ABI_VERSION; }
