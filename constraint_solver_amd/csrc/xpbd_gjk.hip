@@ -34,15 +34,21 @@ namespace {
 constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-struct GjkVerts {
-    double wa[kMaxV][3], wb[kMaxV][3];                                        // world-space vertices
+template <uint32_t V>
+struct GjkVertsT {
+    double wa[V][3], wb[V][3];                                                // world-space vertices (V = capacity per body)
 };
+using GjkVerts = GjkVertsT<kMaxV>;
 
 struct GjkLds : GjkVerts {
     double vw[kMaxEpaVerts][3], va[kMaxEpaVerts][3], vb[kMaxEpaVerts][3];      // polytope vertices + witnesses
     uint32_t fi[kMaxEpaFaces][3];                                              // faces: vertex indices (outward winding)
     double fn[kMaxEpaFaces][3];                                                //        unit normal
     double fd[kMaxEpaFaces];                                                   //        distance of the plane from the origin
+    // ve[a][b] != 0: some face that SEES the new point holds the directed edge a -> b.  Set and cleared again inside every
+    // EPA iteration (all zero in between, zeroed once per workgroup): an edge a -> b of a visible face is on the horizon iff
+    // ve[b][a] == 0 -- one LDS read instead of a search through all faces (which made an iteration O(faces^2) per lane).
+    uint8_t ve[kMaxEpaVerts][kMaxEpaVerts + 4];
 };
 
 struct MVert {
@@ -66,8 +72,8 @@ __device__ __forceinline__ long long total_key(double v)
 
 // support(A, d) - support(B, -d) by a group of L lanes (`lane` = lane inside the group); all lanes of the
 // group return the same value.
-template <uint32_t L>
-__device__ __forceinline__ MVert minkowski_support(const GjkVerts &s, uint32_t na, uint32_t nb, Vec3 d, uint32_t lane)
+template <uint32_t L, class Verts>
+__device__ __forceinline__ MVert minkowski_support(const Verts &s, uint32_t na, uint32_t nb, Vec3 d, uint32_t lane)
 {
     constexpr uint32_t H = L / 2;
     const uint32_t half = lane / H, k = lane % H;
@@ -192,7 +198,8 @@ __device__ __forceinline__ uint32_t closest_face(const GjkLds &s, uint32_t nf, u
 }
 
 // World-space vertices of both bodies of a pair into LDS, `group` lanes cooperating (first half A, second half B).
-__device__ __forceinline__ void stage_world_vertices(GjkVerts &s, const PolytopeTables &t, const ShapeDesc &da, const ShapeDesc &db,
+template <class Verts>
+__device__ __forceinline__ void stage_world_vertices(Verts &s, const PolytopeTables &t, const ShapeDesc &da, const ShapeDesc &db,
                                                      const Frame &fa, const Frame &fb, uint32_t lane, uint32_t group)
 {
     const uint32_t H = group / 2, half = lane / H, k = lane % H;
@@ -216,7 +223,9 @@ __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const M
 // PRETEST (contact pipeline only): as in k_sat_pairs, disjoint tight bounding spheres mean "separated" at once.
 // With `survivors` (the two-pass form, after k_pair_pretest of xpbd_pairs.hip) the groups take their pairs from that
 // list, n_pairs is read from *survivor_count, and block 0 zeroes the counter of the next launch.
-template <uint32_t L, bool PRETEST>
+// V: vertex capacity per body of a pair's LDS record (the launcher picks 16 when no shape has more: 768 bytes per pair
+// instead of 1 536, i.e. twice as many waves per CU for a kernel that waits on LDS round trips and shuffles).
+template <uint32_t L, uint32_t V, bool PRETEST>
 __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                   const uint32_t *__restrict__ survivors, const uint32_t *__restrict__ survivor_count,
@@ -226,8 +235,8 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
                                                   unsigned long long *__restrict__ seeds)
 {
     constexpr uint32_t PW = 64 / L; // pairs per wave
-    __shared__ GjkVerts s_all[PW];
-    GjkVerts &s = s_all[threadIdx.x / L];
+    __shared__ GjkVertsT<V> s_all[PW];
+    GjkVertsT<V> &s = s_all[threadIdx.x / L];
     const uint32_t slot = blockIdx.x * PW + threadIdx.x / L;
     const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
     if (survivors) {
@@ -411,24 +420,34 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         const bool vis1 = f1 < nf && dot(ld3(s.fn, f1), pnt.w - ld3(s.vw, s.fi[f1][0])) > 0.0;
         const unsigned long long mask0 = __ballot(vis0), mask1 = __ballot(vis1);
 
-        // horizon test of my faces' edges: a->b is on the horizon iff no other VISIBLE face holds b->a
+        // horizon test of my faces' edges: a->b is on the horizon iff no other VISIBLE face holds b->a (a face never holds
+        // the reverse of its own edge: its three vertices are distinct, or make_face would have failed).  The visible faces
+        // mark their directed edges in `ve`, every visible face's edge then looks its reverse up, and the marks are
+        // cleared again before anything can leave the loop.
         uint32_t hz[2] = {0, 0};
+        for (uint32_t w = 0; w < 2; ++w) {
+            const uint32_t k = w ? f1 : f0;
+            if (w ? vis1 : vis0)
+                for (uint32_t e = 0; e < 3; ++e)
+                    s.ve[s.fi[k][e]][s.fi[k][e == 2 ? 0 : e + 1]] = 1;
+        }
+        __syncthreads();
         for (uint32_t w = 0; w < 2; ++w) {
             const uint32_t k = w ? f1 : f0;
             if (!(w ? vis1 : vis0))
                 continue;
             for (uint32_t e = 0; e < 3; ++e) {
                 const uint32_t ea = s.fi[k][e], eb = s.fi[k][e == 2 ? 0 : e + 1];
-                bool interior = false;
-                for (uint32_t q = 0; q < nf && !interior; ++q) {
-                    if (q == k || !(((q < 64 ? mask0 : mask1) >> (q & 63u)) & 1ull))
-                        continue;
-                    const uint32_t q0 = s.fi[q][0], q1 = s.fi[q][1], q2 = s.fi[q][2];
-                    interior = (q0 == eb && q1 == ea) || (q1 == eb && q2 == ea) || (q2 == eb && q0 == ea);
-                }
-                if (!interior)
+                if (!s.ve[eb][ea])
                     hz[w] |= 1u << e;
             }
+        }
+        __syncthreads();
+        for (uint32_t w = 0; w < 2; ++w) {
+            const uint32_t k = w ? f1 : f0;
+            if (w ? vis1 : vis0)
+                for (uint32_t e = 0; e < 3; ++e)
+                    s.ve[s.fi[k][e]][s.fi[k][e == 2 ? 0 : e + 1]] = 0;
         }
         // canonical slots: surviving faces keep their order; horizon edges ordered by (face, edge)
         // (exclusive prefix sums over the lanes of 0/1 flags and of 3-bit edge masks: a ballot per bit and a popcount
@@ -540,6 +559,9 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
                                                   const unsigned long long *__restrict__ seeds)
 {
     __shared__ GjkLds s;
+    for (uint32_t k = threadIdx.x; k < sizeof(s.ve) / 4; k += 64)
+        reinterpret_cast<uint32_t *>(&s.ve[0][0])[k] = 0;
+    __syncthreads();
     const uint32_t n_hits = *hit_count;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         *next_hit_count = 0;
@@ -573,8 +595,8 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         sphere_pretest = false; // the survivors have passed it
     }
     auto launch = [&](auto lanes, auto pretest) {
-        constexpr uint32_t L = decltype(lanes)::value;
-        hipLaunchKernelGGL((k_gjk_pairs<L, decltype(pretest)::value>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
+        constexpr uint32_t L = decltype(lanes)::value, V = L == 32 ? kMaxV : 16;
+        hipLaunchKernelGGL((k_gjk_pairs<L, V, decltype(pretest)::value>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
                            frames, pairs, n_pairs, survivors, survivor_count, next_survivor_count, out, manifolds, count, hits, seeds);
     };
     using std::integral_constant;

@@ -14,6 +14,8 @@ for which in after before; do
     timeout -k 10 200 $B --only $part > "$OUT/${which}_$part.json" 2> "$OUT/${which}_$part.err" || exit 1
   done
   timeout -k 10 200 $B --mode contacts --no-cpu-baseline --scene boxes-drop --pitch 1.8 --layers 4 --bodies 262144 > "$OUT/${which}_boxes_pile_262144.json" 2> "$OUT/${which}_boxes_pile.err" || exit 1
+  timeout -k 10 200 $B --mode contacts --no-cpu-baseline --scene stacks --bodies 262144 --narrowphase gjk > "$OUT/${which}_stacks_262144_gjk_epa.json" 2> "$OUT/${which}_stacks_gjk.err" || exit 1
+  timeout -k 10 200 $B --mode contacts --no-cpu-baseline --scene boxes-drop --pitch 1.8 --layers 4 --bodies 65536 --narrowphase gjk > "$OUT/${which}_boxes_pile_65536_gjk_epa.json" 2> "$OUT/${which}_boxes_pile_gjk.err" || exit 1
   if [ -n "$PMC" ]; then
     for part in stacks_262144_sat mixed_pile_65536_sat; do
       for c in FETCH_SIZE WRITE_SIZE; do
