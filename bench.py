@@ -412,6 +412,8 @@ def main():
         if args.backend != "gloo":
             raise SystemExit("--single-device shares one GPU between ranks; RCCL refuses that, use --backend gloo")
         local_rank = 0
+    if args.single_device and world_size > 1:
+        args.no_contacts = True          # the contacts sub-results exchange halos over RCCL, which refuses two ranks on one device
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

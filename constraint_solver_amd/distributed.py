@@ -22,8 +22,13 @@ Scheme
 * The halo is static between re-plans: `halo_margin` is how far any body may travel before
   `replan()` must be called (`replan_every=k` does it every k frames; it re-gathers the whole state
   on the host, O(N), not on the per-substep path).  A body that outruns the margin -- e.g. one
-  flung out of a deep initial overlap at 100 m/s -- silently misses contacts with remote bodies,
-  exactly as a too small broadphase margin would; size the margin for the scene's speeds.
+  flung out of a deep initial overlap at 100 m/s -- could miss contacts with remote bodies, so
+  every step() first reduces, over all ranks, the largest distance any owned body has travelled
+  since the plan and raises HaloMarginExceeded beyond the margin (check_margin=False skips it).
+
+This Python loop is round 1's orchestration, kept as the CPU (gloo) test vehicle; the product path is the
+native multi-GPU world behind the C ABI (csrc/xpbd_multi.cpp, capi.MultiWorld), which does the same inside
+the library with one ncclAllGather per substep.
 """
 import numpy as np
 
@@ -51,6 +56,10 @@ def spatial_order(bodies, shape_id, shape_radius, shape_centroid, pad, halo_marg
     edge = 2.0 * (float(radius.max()) + pad + halo_margin) if len(bodies) else 1.0
     cell = np.floor(centre / edge).astype(np.int64)
     return np.lexsort((np.arange(len(bodies)), cell[:, 2], cell[:, 1], cell[:, 0]))
+
+
+class HaloMarginExceeded(RuntimeError):
+    """A body travelled farther than halo_margin since the halos were planned: remote contacts may have been missed."""
 
 
 class HaloPlan:
@@ -103,10 +112,11 @@ class HaloPlan:
         boundary_slots = np.searchsorted(ids, self.boundary[rank])
         ghost_ids = self.ghosts[rank]
         ghost_slots = np.searchsorted(ids, ghost_ids)
+        owners = self._owner[ghost_ids]
         rows = np.empty(len(ghost_ids), dtype=np.int64)
-        for k, g in enumerate(ghost_ids):
-            o = self._owner[g]
-            rows[k] = o * self.capacity + np.searchsorted(self.boundary[o], g)
+        for o in np.unique(owners):                      # one vectorised search per owning rank
+            mine = owners == o
+            rows[mine] = o * self.capacity + np.searchsorted(self.boundary[o], ghost_ids[mine])
         return ids, owned_mask, boundary_slots, ghost_slots, rows
 
 
@@ -160,8 +170,9 @@ class ShardedContactWorld:
     """One rank of an N-body world with body-body contacts sharded over `world_size` processes."""
 
     def __init__(self, backend, rank, world_size, bodies_global, shape_id_global, shape_radius, shape_centroid,
-                 pad=0.02, halo_margin=0.5, group=None, joints_global=None, order="index", replan_every=0):
+                 pad=0.02, halo_margin=0.5, group=None, joints_global=None, order="index", replan_every=0, check_margin=True):
         self.backend, self.rank, self.world_size, self.group = backend, rank, world_size, group
+        self.check_margin = check_margin
         self.replan_every, self._frames = replan_every, 0   # > 0: re-select the halos every that many step() calls
         self.pad, self.halo_margin = pad, halo_margin
         self.shape_radius, self.shape_centroid = shape_radius, shape_centroid
@@ -202,6 +213,7 @@ class ShardedContactWorld:
         self.send = b.empty(self.plan.capacity)
         self.recv = b.empty(self.plan.capacity * self.world_size)
         self.n_boundary = len(boundary_slots)
+        self._plan_positions = bodies_global[ids][self.owned_mask][:, 31:34].copy()    # of the owned bodies, at plan time
         if self.world_size > 1:
             import torch.distributed as dist
             self._on_gloo = dist.get_backend(self.group) == "gloo"
@@ -224,10 +236,29 @@ class ShardedContactWorld:
         if len(self.ghost_rows):
             b.import_rows(self.ghost_idx, self.ghost_rows, self.recv)
 
+    def max_displacement(self):
+        """Largest distance any owned body of ANY rank has travelled since the plan (a NaN position counts as inf)."""
+        moved = np.linalg.norm(self.backend.download()[self.owned_mask][:, 31:34] - self._plan_positions, axis=1)
+        worst = float(np.nan_to_num(moved, nan=np.inf).max()) if len(moved) else 0.0
+        if self.world_size > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([worst], dtype=torch.float64)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            worst = float(t.item())
+        return worst
+
     def step(self, dt, substeps):
         """xpbd_world_step(dt, substeps) of the whole sharded world (lock step over ranks)."""
         if self.replan_every and self._frames and self._frames % self.replan_every == 0:
             self.replan()
+        if self.check_margin and self.world_size > 1 and self._frames:
+            moved = self.max_displacement()
+            if not moved <= self.halo_margin:
+                raise HaloMarginExceeded("a body has travelled %.3g m since the halos were planned, beyond halo_margin %.3g m: "
+                                         "call replan() more often or raise the margin" % (moved, self.halo_margin))
         self._frames += 1
         h = dt / float(substeps)
         self.backend.begin(dt)

@@ -80,3 +80,34 @@ def test_halo_plan_is_conservative_and_consistent():
             flat[o * plan.capacity: o * plan.capacity + len(plan.boundary[o])] = plan.boundary[o]
         assert np.array_equal(flat[rows], ids[ghost_slots])
         assert np.array_equal(ids[boundary_slots], plan.boundary[r])
+
+
+def _outrun_worker(rank, world_size, port, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from constraint_solver_amd.distributed import HaloMarginExceeded, ShardedContactWorld
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        kind, n = capi.SCENE_BOXES_DROP, 64
+        bodies, sid = hc.line_scene(capi, kind, n, 3, 1.5)
+        bodies[5, 22:25] = [0.0, 0.0, 40.0]                         # 0.67 m per frame against a 0.5 m margin
+        polys, radius, centroid = hc.shape_tables(capi, kind)
+        world = ShardedContactWorld(hc.OracleBackend(ob, hc.POLY_NAMES[kind], 0.02), rank, world_size, bodies, sid, radius, centroid,
+                                    pad=0.02, halo_margin=0.5)
+        world.step(hc.DT, 4)
+        raised = False
+        try:
+            world.step(hc.DT, 4)
+        except HaloMarginExceeded:
+            raised = True                                           # on EVERY rank: the displacement is reduced over all of them
+        world.replan()
+        world.step(hc.DT, 4)
+        np.save(os.path.join(out_dir, "raised%d.npy" % rank), np.array([raised]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_python_halo_loop_detects_a_body_that_outruns_the_margin(tmp_path):
+    mp.spawn(_outrun_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "raised0.npy")[0] and np.load(tmp_path / "raised1.npy")[0]
