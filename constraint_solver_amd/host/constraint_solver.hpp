@@ -420,6 +420,32 @@ struct World {
     }
 };
 
+// xpbd_polytope descriptors of a list of Polytopes (the descriptors point into the object's own arrays).
+struct PolytopeDescs {
+    std::vector<std::vector<double>> verts;
+    std::vector<std::vector<uint32_t>> edges, foff, fidx;
+    std::vector<xpbd_polytope> desc;
+    explicit PolytopeDescs(const std::vector<geometry::Polytope> &shapes)
+        : verts(shapes.size()), edges(shapes.size()), foff(shapes.size()), fidx(shapes.size()), desc(shapes.size())
+    {
+        for (size_t s = 0; s < shapes.size(); ++s) {
+            const geometry::Polytope &p = shapes[s];
+            for (const Vec3 &x : p.vertices)
+                verts[s].insert(verts[s].end(), {x.x, x.y, x.z});
+            for (const auto &e : p.edges)
+                edges[s].insert(edges[s].end(), {e[0], e[1]});
+            foff[s].push_back(0);
+            for (const auto &f : p.faces) {
+                fidx[s].insert(fidx[s].end(), f.begin(), f.end());
+                foff[s].push_back((uint32_t)fidx[s].size());
+            }
+            desc[s] = xpbd_polytope{verts[s].data(), edges[s].data(), foff[s].data(), fidx[s].data(),
+                                    (uint32_t)p.vertices.size(), (uint32_t)p.edges.size(), (uint32_t)p.faces.size(), 0,
+                                    {p.centroid.x, p.centroid.y, p.centroid.z}};
+        }
+    }
+};
+
 // N-body generalisation of World: one batched xpbd_world per GPU.
 class BatchWorld {
   public:
@@ -446,25 +472,8 @@ class BatchWorld {
     // EXTENSION: full topology, needed by XPBD_MODE_CONTACTS (body-body contacts; not in the reference).
     void set_polytopes(const std::vector<geometry::Polytope> &shapes)
     {
-        std::vector<std::vector<double>> verts(shapes.size());
-        std::vector<std::vector<uint32_t>> edges(shapes.size()), foff(shapes.size()), fidx(shapes.size());
-        std::vector<xpbd_polytope> desc(shapes.size());
-        for (size_t s = 0; s < shapes.size(); ++s) {
-            const geometry::Polytope &p = shapes[s];
-            for (const Vec3 &x : p.vertices)
-                verts[s].insert(verts[s].end(), {x.x, x.y, x.z});
-            for (const auto &e : p.edges)
-                edges[s].insert(edges[s].end(), {e[0], e[1]});
-            foff[s].push_back(0);
-            for (const auto &f : p.faces) {
-                fidx[s].insert(fidx[s].end(), f.begin(), f.end());
-                foff[s].push_back((uint32_t)fidx[s].size());
-            }
-            desc[s] = xpbd_polytope{verts[s].data(), edges[s].data(), foff[s].data(), fidx[s].data(),
-                                    (uint32_t)p.vertices.size(), (uint32_t)p.edges.size(), (uint32_t)p.faces.size(), 0,
-                                    {p.centroid.x, p.centroid.y, p.centroid.z}};
-        }
-        check(xpbd_world_set_polytopes(w_, desc.data(), (uint32_t)desc.size()));
+        const PolytopeDescs d(shapes);
+        check(xpbd_world_set_polytopes(w_, d.desc.data(), (uint32_t)d.desc.size()));
     }
     void upload(const std::vector<rigid::Rigid> &bodies, const std::vector<uint32_t> &shape_id)
     {
@@ -507,6 +516,79 @@ class BatchWorld {
 
   private:
     xpbd_world *w_ = nullptr;
+};
+
+// EXTENSION: the N-body contact world sharded over the GPUs of one node, all shards driven by THIS process -- what a
+// Rust `World::integrate` (src/world.rs:34-43) would hold in place of its two `solver::step` calls.  One call per frame;
+// the library owns a stream and an RCCL communicator per device, plans the halos, exchanges them after every substep and
+// throws XPBD_E_HALO when a body outruns the halo margin (automatic re-plans by default).  With fewer visible devices than
+// shards the shards share `first_device` and exchange by peer copies (XPBD_TRANSPORT_LOCAL): the one-GPU rehearsal.
+class ShardedWorld {
+  public:
+    ShardedWorld(uint32_t n_shards, int first_device = 0, double halo_margin = 0.5, bool auto_replan = true, double contact_pad = 0.02,
+                 uint32_t narrowphase = XPBD_NARROWPHASE_SAT)
+    {
+        const int visible = xpbd_device_count();
+        const bool one_each = visible >= first_device + (int)n_shards;
+        std::vector<int32_t> devices(n_shards);
+        for (uint32_t k = 0; k < n_shards; ++k)
+            devices[k] = one_each ? first_device + (int)k : first_device;
+        uint8_t id[XPBD_COMM_ID_BYTES] = {0};
+        xpbd_multi_config cfg;
+        xpbd_multi_config_default(&cfg);
+        cfg.n_ranks = cfg.n_local = n_shards;
+        cfg.devices = devices.data();
+        cfg.transport = one_each && n_shards > 1 ? XPBD_TRANSPORT_RCCL : XPBD_TRANSPORT_LOCAL;
+        if (cfg.transport == XPBD_TRANSPORT_RCCL) {
+            check(xpbd_comm_unique_id(id));
+            cfg.comm_id = id;
+        }
+        cfg.flags = auto_replan ? XPBD_MULTI_AUTO_REPLAN : 0u;
+        cfg.contact_pad = contact_pad;
+        cfg.halo_margin = halo_margin;
+        cfg.narrowphase = narrowphase;
+        check(xpbd_multi_world_create(&w_, &cfg));
+        rccl_ = cfg.transport == XPBD_TRANSPORT_RCCL;
+    }
+    ~ShardedWorld() { xpbd_multi_world_destroy(w_); }
+    ShardedWorld(const ShardedWorld &) = delete;
+    ShardedWorld &operator=(const ShardedWorld &) = delete;
+
+    void set_polytopes(const std::vector<geometry::Polytope> &shapes)
+    {
+        const PolytopeDescs d(shapes);
+        check(xpbd_multi_world_set_polytopes(w_, d.desc.data(), (uint32_t)d.desc.size()));
+    }
+    // bodies in an order whose contiguous index ranges are compact in space (grid rows, spatial-hash cell order)
+    void upload(const std::vector<rigid::Rigid> &bodies, const std::vector<uint32_t> &shape_id, const std::vector<xpbd_joint> &joints = {})
+    {
+        if (!shape_id.empty() && shape_id.size() != bodies.size())
+            throw Error(XPBD_E_INVALID, "shape_id size mismatch");
+        n_ = (uint32_t)bodies.size();
+        check(xpbd_multi_world_upload(w_, bodies.empty() ? nullptr : bodies[0].c(), shape_id.empty() ? nullptr : shape_id.data(), 0, n_, n_,
+                                      joints.empty() ? nullptr : joints.data(), (uint32_t)joints.size()));
+    }
+    void integrate(double dt, uint32_t substeps) { check(xpbd_multi_world_step(w_, dt, substeps)); }
+    void replan() { check(xpbd_multi_world_replan(w_)); }
+    void synchronize() { check(xpbd_multi_world_synchronize(w_)); }
+    void download(std::vector<rigid::Rigid> &bodies)
+    {
+        bodies.resize(n_);
+        check(xpbd_multi_world_download(w_, bodies.empty() ? nullptr : bodies[0].c(), n_));
+    }
+    // {bodies of the world, owned here, ghosts, boundary bodies, rows per rank of the all-gather, plans made}
+    std::vector<uint64_t> halo_stats(double *max_displacement = nullptr)
+    {
+        std::vector<uint64_t> out(6);
+        check(xpbd_multi_world_halo_stats(w_, out.data(), max_displacement));
+        return out;
+    }
+    bool over_rccl() const { return rccl_; }
+
+  private:
+    xpbd_multi_world *w_ = nullptr;
+    uint32_t n_ = 0;
+    bool rccl_ = false;
 };
 
 // The reference app's state history (src/app.rs:48, 206-212): `states` lives on the device as the world's history,

@@ -4,7 +4,10 @@
 //
 //   xpbd_headless --bodies 262144 --substeps 20 --frames 10 [--scene boxes|mixed|boxes-drop|mixed-drop|stacks]
 //                 [--seed 1] [--mode fused|substep|contacts] [--device 0] [--dump poses.bin]
-//                 [--history] [--rewind K]
+//                 [--history] [--rewind K] [--shards N]
+// --shards N (with --mode contacts): the world sharded over N GPUs driven by this one process (world::ShardedWorld over
+// xpbd_multi_world_*: devices --device .. --device + N - 1 over RCCL; with fewer visible devices all shards share --device and
+// exchange by peer copies -- the one-GPU rehearsal).  The dump then equals the unsharded run's, byte for byte.
 // --history keeps every frame on the device like the reference app's `states` vector (src/app.rs:48) and steps through
 // world::Timeline; --rewind K then scrubs back to state K (0 = the initial world) before the dump.
 #include <chrono>
@@ -19,7 +22,7 @@ using namespace constraint_solver;
 
 int main(int argc, char **argv)
 {
-    uint32_t bodies = 4096, substeps = 20, frames = 10, warmup = 2;
+    uint32_t bodies = 4096, substeps = 20, frames = 10, warmup = 2, shards = 0;
     bool history = false;
     long rewind = -1;
     uint64_t seed = 1;
@@ -47,6 +50,7 @@ int main(int argc, char **argv)
         else if (const char *v = val("--mode")) mode = std::strcmp(v, "substep") == 0 ? XPBD_MODE_PER_SUBSTEP : std::strcmp(v, "contacts") == 0 ? XPBD_MODE_CONTACTS : XPBD_MODE_FUSED;
         else if (const char *v = val("--dump")) dump = v;
         else if (const char *v = val("--rewind")) rewind = std::strtol(v, nullptr, 10);
+        else if (const char *v = val("--shards")) shards = (uint32_t)std::strtoul(v, nullptr, 10);
         else if (std::strcmp(argv[i], "--history") == 0) history = true;
         else {
             std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -58,6 +62,42 @@ int main(int argc, char **argv)
         std::vector<uint32_t> shape_id;
         scene::generate(kind, seed, scene::default_grid_width(bodies), 0, bodies, state, shape_id);
 
+        const double dt = 1.0 / 60.0; // FRAME_TIME, src/app.rs:15
+        if (shards) {
+            if (mode != XPBD_MODE_CONTACTS || history) {
+                std::fprintf(stderr, "--shards needs --mode contacts and no --history\n");
+                return 2;
+            }
+            world::ShardedWorld w(shards, device);
+            w.set_polytopes(scene::shapes_of(kind));
+            w.upload(state, shape_id);
+            for (uint32_t f = 0; f < warmup; ++f)
+                w.integrate(dt, substeps);
+            w.synchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t f = 0; f < frames; ++f)
+                w.integrate(dt, substeps);
+            w.synchronize();
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            w.download(state);
+            double moved = 0.0;
+            const auto halo = w.halo_stats(&moved);
+            std::printf("{\"bodies\": %u, \"substeps\": %u, \"frames\": %u, \"mode\": \"contacts\", \"shards\": %u, \"transport\": \"%s\", "
+                        "\"seconds\": %.6f, \"body_substeps_per_s\": %.4e, \"ghosts\": %llu, \"boundary\": %llu, \"plans\": %llu, "
+                        "\"max_displacement\": %.4f}\n",
+                        bodies, substeps, frames, shards, w.over_rccl() ? "rccl" : "local", sec, (double)bodies * substeps * frames / sec,
+                        (unsigned long long)halo[2], (unsigned long long)halo[3], (unsigned long long)halo[5], moved);
+            if (!dump.empty()) {
+                FILE *fp = std::fopen(dump.c_str(), "wb");
+                if (!fp) {
+                    std::perror("dump");
+                    return 1;
+                }
+                std::fwrite(state.data(), sizeof(rigid::Rigid), state.size(), fp);
+                std::fclose(fp);
+            }
+            return 0;
+        }
         xpbd_config cfg;
         xpbd_config_default(&cfg);
         cfg.device = device;
@@ -69,7 +109,6 @@ int main(int argc, char **argv)
             w.set_shapes(scene::shapes_of(kind));
         w.upload(state, shape_id);
 
-        const double dt = 1.0 / 60.0; // FRAME_TIME, src/app.rs:15
         if (history)
             warmup = 0; // state 0 of the timeline is the initial world
         for (uint32_t f = 0; f < warmup; ++f)

@@ -33,3 +33,20 @@ def test_headless_driver_runs_on_the_gpu(tmp_path, extra):
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["bodies"] == 4096 and out["body_substeps_per_s"] > 1e6
     assert dump.stat().st_size == 4096 * 304
+
+
+@pytest.mark.gpu
+def test_headless_driver_sharded_world_equals_the_single_world(tmp_path):
+    """--shards N: the compiled host side above the multi-GPU ABI (world::ShardedWorld over xpbd_multi_world_*), here
+    with the shards sharing the box's one device.  Its dump equals the unsharded run's, byte for byte."""
+    base = [EXE, "--bodies", "4096", "--substeps", "10", "--frames", "4", "--warmup", "1", "--mode", "contacts", "--scene", "stacks"]
+    one, three = tmp_path / "one.bin", tmp_path / "three.bin"
+    p = subprocess.run(base + ["--dump", str(one)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    p = subprocess.run(base + ["--shards", "3", "--dump", str(three)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["shards"] == 3 and out["ghosts"] > 0 and out["transport"] in ("local", "rccl")
+    assert one.read_bytes() == three.read_bytes()
+    p = subprocess.run(base[:-4] + ["--shards", "2"], capture_output=True, text=True, timeout=60)   # not in contacts mode
+    assert p.returncode == 2
