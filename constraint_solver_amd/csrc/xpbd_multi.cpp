@@ -296,7 +296,7 @@ int all_gather_host(xpbd_multi_world *mw, const std::vector<const void *> &send,
     out.assign((size_t)mw->n_ranks * bytes, 0);
     if (bytes == 0)
         return XPBD_OK;
-    if (mw->all_local()) { // every rank is here: no device round trip needed
+    if (mw->all_local() && !(mw->flags & XPBD_MULTI_PLAN_THROUGH_DEVICE)) { // every rank is here: no device round trip needed
         for (size_t k = 0; k < mw->shards.size(); ++k)
             std::memcpy(out.data() + (size_t)mw->shards[k].rank * bytes, send[k], bytes);
         return XPBD_OK;
@@ -646,7 +646,7 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: XPBD_TRANSPORT_RCCL needs comm_id (xpbd_comm_unique_id on one rank, handed to all)");
     if (!(cfg->contact_pad >= 0.0) || !(cfg->halo_margin > 0.0) || cfg->contact_pad > 1.0e6 || cfg->halo_margin > 1.0e6)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: contact_pad %g / halo_margin %g", cfg->contact_pad, cfg->halo_margin);
-    if (cfg->flags & ~XPBD_MULTI_AUTO_REPLAN)
+    if (cfg->flags & ~(XPBD_MULTI_AUTO_REPLAN | XPBD_MULTI_PLAN_THROUGH_DEVICE))
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: unknown flags 0x%x", cfg->flags);
     if (cfg->narrowphase != XPBD_NARROWPHASE_SAT && cfg->narrowphase != XPBD_NARROWPHASE_GJK_EPA)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: unknown narrowphase %u", cfg->narrowphase);

@@ -128,6 +128,7 @@ pub const XPBD_COMM_ID_BYTES: usize = 128;
 pub const XPBD_TRANSPORT_RCCL: u32 = 0;
 pub const XPBD_TRANSPORT_LOCAL: u32 = 1;
 pub const XPBD_MULTI_AUTO_REPLAN: u32 = 1;
+pub const XPBD_MULTI_PLAN_THROUGH_DEVICE: u32 = 2;
 pub const XPBD_E_HALO: c_int = -7;
 
 /// xpbd_multi_config (include/xpbd.h)

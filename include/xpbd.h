@@ -307,6 +307,8 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
 #define XPBD_TRANSPORT_RCCL  0u
 #define XPBD_TRANSPORT_LOCAL 1u         /* needs n_local == n_ranks */
 #define XPBD_MULTI_AUTO_REPLAN 1u
+#define XPBD_MULTI_PLAN_THROUGH_DEVICE 2u /* diagnostics: the plan-time all-gathers go through the device transport even when
+                                           * every rank lives in this process (the path a one-process-per-GPU run takes) */
 
 typedef struct xpbd_multi_config {
     uint32_t struct_size;   /* = sizeof(xpbd_multi_config) */

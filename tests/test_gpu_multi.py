@@ -30,9 +30,9 @@ def single(bodies, sid, kind, frames, substeps, joints=None, narrowphase=capi.NA
 
 
 def sharded(bodies, sid, kind, n_ranks, frames, substeps, joints=None, narrowphase=capi.NARROWPHASE_SAT, margin=0.75, replan_at=(),
-            auto_replan=False, pad=0.02):
+            auto_replan=False, pad=0.02, plan_through_device=False):
     with capi.MultiWorld(n_ranks, devices=[0] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=margin, narrowphase=narrowphase,
-                         auto_replan=auto_replan, pad=pad) as mw:
+                         auto_replan=auto_replan, pad=pad, plan_through_device=plan_through_device) as mw:
         mw.set_polytopes(capi.scene_polytopes(kind))
         mw.upload(bodies, sid, 0, len(bodies), joints)
         stats0 = mw.halo_stats()
@@ -43,11 +43,14 @@ def sharded(bodies, sid, kind, n_ranks, frames, substeps, joints=None, narrowpha
         return mw.download(), stats0, mw.halo_stats(), mw.contact_stats()
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3])
-def test_sharded_equals_single_device_and_oracle(n_ranks):
+@pytest.mark.parametrize("n_ranks,through_device", [(2, False), (3, False), (3, True)])
+def test_sharded_equals_single_device_and_oracle(n_ranks, through_device):
+    """(through_device: the plan-time all-gathers -- cell keys, boundary lists, boundary records -- take the staged device path
+    of a one-process-per-GPU run instead of the in-process shortcut)"""
     kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 96, 6, 40
     bodies, sid = line_scene(capi, kind, n, 11, 1.3)
-    got, s0, s1, cstats = sharded(bodies, sid, kind, n_ranks, frames, substeps, replan_at=(25,), auto_replan=True)
+    got, s0, s1, cstats = sharded(bodies, sid, kind, n_ranks, frames, substeps, replan_at=(25,), auto_replan=True,
+                                  plan_through_device=through_device)
     assert s0["ghosts"] > 0 and s0["boundary"] > 0 and s1["plans"] >= 3      # the explicit one and the automatic ones
     one, one_stats = single(bodies, sid, kind, frames, substeps)
     assert one_stats[1] > 0                                              # body-body contacts did happen
@@ -117,12 +120,15 @@ def test_rccl_transport_with_a_one_rank_communicator():
     bodies, sid = line_scene(capi, kind, n, 2, 1.3)
     cid = capi.comm_unique_id()
     assert len(cid) == capi.COMM_ID_BYTES and any(cid)
-    with capi.MultiWorld(1, devices=[0], transport=capi.TRANSPORT_RCCL, comm_id=cid) as mw:
+    with capi.MultiWorld(1, devices=[0], transport=capi.TRANSPORT_RCCL, comm_id=cid, plan_through_device=True) as mw:
         mw.set_polytopes(capi.scene_polytopes(kind))
-        mw.upload(bodies, sid, 0, n)
+        mw.upload(bodies, sid, 0, n)                        # the plan's all-gathers go through ncclAllGather as well
         for _ in range(frames):
             mw.step(DT, substeps)
+        mw.replan()
+        mw.step(DT, substeps)
         got, stats = mw.download(), mw.halo_stats()
+    frames += 1
     assert stats["ghosts"] == 0 and stats["owned"] == n
     one, _ = single(bodies, sid, kind, frames, substeps)
     assert bits_equal(got, one)
