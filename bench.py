@@ -186,11 +186,21 @@ def contacts_workload(scene, bodies_per_gpu, substeps, narrowphase, joints, pitc
                ", %d distance joints" % joints if joints else ""))
 
 
+def scene_grid_width(capi, kind, bodies_per_rank, total):
+    """Grid width of a contact scene.  Index ranges are the shards, so the grid is laid out for ONE rank's bodies to be
+    about square and the ranks' slabs to follow each other along y: box stacks (16 bodies per grid point) 128 columns wide
+    for 262 144 bodies per rank -- the generator's default (the square root of the BODY count) would make that world 16 times
+    wider than deep and a rank's slab a dozen rows of which four are halo."""
+    if kind == capi.SCENE_BOX_STACKS:
+        return capi.default_grid_width(max(bodies_per_rank // 16, 1))
+    return capi.default_grid_width(total)
+
+
 def contacts_scene(capi, args, kind, total, pitch, layers):
     """All `total` bodies of a contact scene: the seeded grid scene at `pitch`, or (layers > 0) the same bodies as a pile."""
     if layers:
         return capi.scene_pile(kind, args.seed, total, pitch, layers)
-    state, shape_id = capi.scene_generate(kind, args.seed, total)
+    state, shape_id = capi.scene_generate(kind, args.seed, total, grid_w=scene_grid_width(capi, kind, total, total))
     if pitch != 2.0:
         state[:, 31:33] *= pitch / 2.0
     return state, shape_id
@@ -225,7 +235,7 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
     world.set_contact_pad(pad)
     world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT)
     world.upload(state, shape_id)
-    joints = chain_joints(capi, np, joints_n, count, pitch, capi.default_grid_width(total)) if joints_n else None
+    joints = chain_joints(capi, np, joints_n, count, pitch, scene_grid_width(capi, kind, total, total)) if joints_n else None
     if joints is not None:
         world.set_joints(joints)
     stream = torch.cuda.current_stream()
@@ -302,13 +312,13 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
             part, sid = capi.scene_pile(kind, args.seed, total, pitch, layers, first=first, count=count,
                                         y_offset=r * capi.pile_depth(count, pitch, layers))
         else:
-            part, sid = capi.scene_generate(kind, args.seed, total, first=first, count=count)
+            part, sid = capi.scene_generate(kind, args.seed, total, first=first, count=count, grid_w=scene_grid_width(capi, kind, bodies, total))
             if pitch != 2.0:
                 part[:, 31:33] *= pitch / 2.0
         parts.append(part)
         sids.append(sid)
     state, shape_id = np.concatenate(parts), np.concatenate(sids)
-    joints = chain_joints(capi, np, joints_n * n_ranks, total, pitch, capi.default_grid_width(total)) if joints_n else None
+    joints = chain_joints(capi, np, joints_n * n_ranks, total, pitch, scene_grid_width(capi, kind, bodies, total)) if joints_n else None
     if local_shards:
         world = capi.MultiWorld(n_ranks, devices=[local_rank] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=0.5,
                                 narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT, auto_replan=True)
@@ -437,10 +447,15 @@ def main():
     # box stacks; configs[2]: 65 536 mixed convex polyhedra on the GJK/EPA path)
     sub_runs = {
         "stacks_262144_sat": dict(scene="stacks", bodies=262144, narrowphase="sat", joints_n=0, pitch=2.0),
+        "boxes_pile_262144_sat": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=0, pitch=1.8, layers=4),
         "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4),
         "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4),
         "boxes_262144_joints_65536": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=65536, pitch=2.0),
     }
+    if world_size > 1:
+        # the mixed piles keep shedding light tetrahedra at > 100 m/s ("Scenes"): several metres per frame,
+        # beyond any halo margin worth having -- the sharded world would (rightly) refuse them with XPBD_E_HALO
+        sub_runs = {k: v for k, v in sub_runs.items() if not k.startswith("mixed_pile")}
     if args.only and args.only != "pinned":
         if args.only not in sub_runs:
             raise SystemExit("--only: one of pinned, %s" % ", ".join(sub_runs))

@@ -32,6 +32,7 @@ if has trace; then
   trace mixed_gjk --only mixed_pile_65536_gjk_epa
   trace mixed_sat --only mixed_pile_65536_sat
   trace joints --only boxes_262144_joints_65536
+  trace boxes_pile --only boxes_pile_262144_sat
 fi
 if has pmc; then
   pmc valu "--only pinned" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU

@@ -52,3 +52,32 @@ def test_far_and_nan_centres_are_clamped_not_dropped():
     assert keys[0] == keys[4] and len(set(keys.tolist())) == 4
     ghosts, boundary = capi.halo_plan(keys, 2, 0)                   # rank 0 owns bodies 0..2, rank 1 bodies 3, 4
     assert ghosts.tolist() == [4] and boundary.tolist() == [0]      # body 4 shares body 0's cell; the far ones reach nobody
+
+
+def test_native_plan_is_conservative_and_symmetric():
+    """Whatever the layout: (1) every remote body whose bounding sphere comes within 2 * (pad + margin) of an owned body's
+    sphere is among the rank's ghosts -- nothing that could touch an owned body before the next plan is missing; (2) a body
+    is on its owner's boundary list iff some other rank mirrors it (the all-gather rows and the ghost lists agree)."""
+    rng = np.random.default_rng(5)
+    n, world_size, pad, margin = 600, 4, 0.02, 0.25
+    centre = rng.uniform(0, 14, (n, 3))
+    radius = rng.uniform(0.3, 0.9, n)
+    edge = 2.0 * (float(radius.max()) + pad + margin)
+    keys = np.array([capi.halo_cell_key(c, edge) for c in centre], dtype=np.int64)
+    reach = radius[:, None] + radius[None, :] + 2 * (pad + margin)
+    close = np.linalg.norm(centre[:, None, :] - centre[None, :, :], axis=2) < reach
+    base, extra = divmod(n, world_size)
+    mirrored = np.zeros(n, dtype=bool)
+    boundaries = []
+    for rank in range(world_size):
+        first = rank * base + min(rank, extra)
+        count = base + (1 if rank < extra else 0)
+        ghosts, boundary = capi.halo_plan(keys, world_size, rank)
+        assert np.all(np.diff(ghosts.astype(np.int64)) > 0) and np.all(np.diff(boundary.astype(np.int64)) > 0)
+        assert not np.any((ghosts >= first) & (ghosts < first + count)) and np.all((boundary >= first) & (boundary < first + count))
+        present = set(ghosts.tolist()) | set(range(first, first + count))
+        for i in range(first, first + count):
+            assert set(np.nonzero(close[i])[0].tolist()) <= present
+        mirrored[ghosts] = True
+        boundaries.append(boundary)
+    assert np.array_equal(np.nonzero(mirrored)[0], np.sort(np.concatenate(boundaries)))
