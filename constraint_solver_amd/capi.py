@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
     "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
     "xpbd_multi_world_synchronize", "xpbd_multi_world_download", "xpbd_multi_world_halo_stats", "xpbd_multi_world_contact_stats",
-    "xpbd_halo_cell_key", "xpbd_halo_plan",
+    "xpbd_halo_cell_key", "xpbd_halo_plan", "xpbd_halo_plan_far",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
 
@@ -147,7 +147,7 @@ def hip_lib():
         L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
         L.xpbd_selftest_hbm_copy.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, _f64p]
         L.xpbd_world_snapshot_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-        L.xpbd_world_max_displacement2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.xpbd_world_max_displacement2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xpbd_comm_unique_id.argtypes = [C.c_char_p]
         L.xpbd_multi_config_default.argtypes = [C.POINTER(MultiConfig)]
         L.xpbd_multi_config_default.restype = None
@@ -519,6 +519,17 @@ def halo_plan(cell_keys, n_ranks, rank, joints=None):
     _check(hip_lib().xpbd_halo_plan(keys.ctypes.data_as(C.POINTER(C.c_int64)), len(keys), n_ranks, rank, j.ctypes.data if j.size else None,
                                     j.size, _u32(ghosts), C.byref(ng), _u32(boundary), C.byref(nb), len(keys)))
     return ghosts[: ng.value].copy(), boundary[: nb.value].copy()
+
+
+def halo_plan_far(cell_keys, n_ranks, rank):
+    """Per owned body of `rank` (index order): 1 if the plan classes it as far from every foreign body (host-only)."""
+    keys = np.ascontiguousarray(cell_keys, dtype=np.int64)
+    far = np.zeros(len(keys), dtype=np.uint8)
+    n = C.c_uint32(0)
+    L = hip_lib()
+    L.xpbd_halo_plan_far.argtypes = [C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _u32p]
+    _check(L.xpbd_halo_plan_far(keys.ctypes.data_as(C.POINTER(C.c_int64)), len(keys), n_ranks, rank, far.ctypes.data, len(keys), C.byref(n)))
+    return far[: n.value].copy()
 
 
 def step_one(rigid, verts_xyz, dt, substeps):

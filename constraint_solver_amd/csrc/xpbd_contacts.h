@@ -113,10 +113,11 @@ hipError_t launch_export_dynamic(const BodyArrays &b, const uint32_t *indices, u
 hipError_t launch_import_dynamic(const BodyArrays &b, const uint32_t *indices, const uint32_t *rows, uint32_t n, const double *buf,
                                  hipStream_t stream); // rows: NULL = row k of buf for entry k
 
-// Halo validity: snapshot[3k..3k+2] = position of body indices[k]; *out = max(*out, max_k |position - snapshot|^2).
+// Halo validity: snapshot[3k..3k+2] = position of body indices[k]; *out = max(*out, max_k scale[k] * |position - snapshot|^2)
+// (scale == NULL: 1).
 hipError_t launch_snapshot_positions(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *snapshot, hipStream_t stream);
-hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *snapshot, double *out,
-                                    hipStream_t stream);
+hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *snapshot, const double *scale,
+                                    double *out, hipStream_t stream);
 
 // Exclusive scan of data[0..n) in place; data[n] receives the total.  scratch: >= n/1024 + 2 uint32.
 hipError_t launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *scratch, hipStream_t stream);

@@ -927,8 +927,10 @@ __global__ void k_snapshot_positions(BodyArrays b, const uint32_t *__restrict__ 
 // ... and the largest squared distance any of them has travelled since: *out = max(*out, max_k |pos_k - snapshot_k|^2).
 // Non-negative doubles order like their bit patterns, so the maximum is an integer atomicMax (one per workgroup); a NaN
 // position counts as +inf.
+// (scale: optional per-entry factor on the squared distance, e.g. 1 / allowance^2: the result is then a ratio)
 __global__ void __launch_bounds__(kBlock) k_max_displacement2(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n,
-                                                              const double *__restrict__ snapshot, double *__restrict__ out)
+                                                              const double *__restrict__ snapshot, const double *__restrict__ scale,
+                                                              double *__restrict__ out)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     double d2 = 0.0;
@@ -936,6 +938,8 @@ __global__ void __launch_bounds__(kBlock) k_max_displacement2(BodyArrays b, cons
         const Vec3 p = load3(b.dyn, D_POS, b.stride, indices[k]);
         const Vec3 d = p - Vec3{snapshot[3 * (size_t)k + 0], snapshot[3 * (size_t)k + 1], snapshot[3 * (size_t)k + 2]};
         d2 = dot(d, d);
+        if (scale)
+            d2 *= scale[k];
         if (!(d2 <= DBL_MAX))
             d2 = __longlong_as_double(0x7FF0000000000000ll);
     }
@@ -1113,11 +1117,11 @@ hipError_t launch_snapshot_positions(const BodyArrays &b, const uint32_t *indice
     return hipGetLastError();
 }
 
-hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *snapshot, double *out,
-                                    hipStream_t stream)
+hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *snapshot, const double *scale,
+                                    double *out, hipStream_t stream)
 {
     if (n)
-        hipLaunchKernelGGL(k_max_displacement2, dim3(blocks_for(n)), dim3(kBlock), 0, stream, b, indices, n, snapshot, out);
+        hipLaunchKernelGGL(k_max_displacement2, dim3(blocks_for(n)), dim3(kBlock), 0, stream, b, indices, n, snapshot, scale, out);
     return hipGetLastError();
 }
 

@@ -17,7 +17,9 @@
 // remote contact may have been missed) instead of silently losing contacts, and with XPBD_MULTI_AUTO_REPLAN the halos are
 // re-planned at half the margin.
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -118,74 +120,124 @@ struct DevBuf {
 struct HaloPlanner {
     uint32_t n = 0, w = 0;
     const int64_t *keys = nullptr;
-    std::unordered_map<int64_t, uint64_t> cell_ranks; // cell -> bit set of the ranks that own a body in it
-
-    void index_cells()
-    {
-        cell_ranks.clear();
-        cell_ranks.reserve((size_t)n / 2 + 16);
-        for (uint32_t g = 0; g < n; ++g)
-            cell_ranks[keys[g]] |= 1ull << owner_of(g, n, w);
-    }
 
     // ghosts: remote bodies in a cell within one cell of a cell this rank owns a body in (ascending);
     // boundary: this rank's bodies in a cell within one cell of a cell another rank owns a body in (ascending).
     // A joint between an owned and a remote body puts the remote one among the ghosts and the owned one on the boundary.
+    // far (optional, one flag per owned body): no cell within two cells of the body's holds a foreign body.  Such a body
+    // may travel halo_margin + edge / 2 before it can meet a body this rank does not mirror (any foreign body starts more
+    // than two cell edges away, and 2 * (margin + edge / 2) = edge + 2 * margin is less than the 2 * edge - 2 r - pad the
+    // two would have to close), the others halo_margin.
+    // Cost: one pass over ALL cell keys that only decodes them; everything hashed lies within two cells of this rank's
+    // bounding box (the foreign cells next to the slab) or belongs to the rank itself.
     void plan_rank(uint32_t rank, const xpbd_joint *joints, uint32_t n_joints, std::vector<uint32_t> &ghosts,
-                   std::vector<uint32_t> &boundary) const
+                   std::vector<uint32_t> &boundary, std::vector<uint8_t> *far = nullptr) const
     {
         const Range own = shard_range(n, rank, w);
-        std::unordered_set<int64_t> reach;
-        {
-            std::unordered_set<int64_t> own_cells;
-            for (uint32_t g = own.first; g < own.first + own.count; ++g)
-                own_cells.insert(keys[g]);
-            reach.reserve(own_cells.size() * 4 + 16);
-            for (int64_t key : own_cells) {
+        const uint32_t own_end = own.first + own.count;
+        // this rank's unique cells and their bounding box
+        std::unordered_map<int64_t, uint8_t> own_cells; // cell -> some other rank owns a body within one cell of it
+        own_cells.reserve((size_t)own.count / 2 + 16);
+        int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+        for (uint32_t g = own.first; g < own_end; ++g)
+            if (own_cells.emplace(keys[g], 0).second) {
                 int64_t c[3];
-                cell_of_key(key, c);
-                for (int dx = -1; dx <= 1; ++dx)
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int dz = -1; dz <= 1; ++dz)
-                            reach.insert(cell_key(c[0] + dx, c[1] + dy, c[2] + dz));
+                cell_of_key(keys[g], c);
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::min(lo[a], c[a]);
+                    hi[a] = std::max(hi[a], c[a]);
+                }
             }
-        }
-        std::vector<uint8_t> is_ghost(n, 0), is_boundary(own.count, 0);
-        for (uint32_t g = 0; g < n; ++g)
-            if ((g < own.first || g >= own.first + own.count) && reach.count(keys[g]))
-                is_ghost[g] = 1;
-        const uint64_t others = ~(1ull << rank);
-        for (uint32_t k = 0; k < own.count; ++k) {
+        // the foreign bodies within two cells of that box: their cells, and (within one cell of an own cell) the ghosts
+        std::unordered_set<int64_t> foreign_cells;
+        std::vector<uint32_t> candidates; // foreign bodies inside the box grown by one cell: the possible ghosts
+        for (uint32_t g = 0; g < n; ++g) {
+            if (own.count && g == own.first) {
+                g = own_end - 1; // skip the own range
+                continue;
+            }
             int64_t c[3];
-            cell_of_key(keys[own.first + k], c);
+            cell_of_key(keys[g], c);
+            bool in2 = true, in1 = true;
+            for (int a = 0; a < 3; ++a) {
+                in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
+                in1 = in1 && c[a] >= lo[a] - 1 && c[a] <= hi[a] + 1;
+            }
+            if (!in2 || own.count == 0)
+                continue;
+            foreign_cells.insert(keys[g]);
+            if (in1)
+                candidates.push_back(g);
+        }
+        // per own cell: a foreign body within one cell?  (then all its bodies are boundary bodies)
+        for (auto &cell : own_cells) {
+            int64_t c[3];
+            cell_of_key(cell.first, c);
             bool seen = false;
             for (int dx = -1; dx <= 1 && !seen; ++dx)
                 for (int dy = -1; dy <= 1 && !seen; ++dy)
-                    for (int dz = -1; dz <= 1 && !seen; ++dz) {
-                        const auto it = cell_ranks.find(cell_key(c[0] + dx, c[1] + dy, c[2] + dz));
-                        seen = it != cell_ranks.end() && (it->second & others);
-                    }
-            is_boundary[k] = seen;
+                    for (int dz = -1; dz <= 1 && !seen; ++dz)
+                        seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
+            cell.second = seen;
+        }
+        std::vector<uint8_t> is_boundary(own.count, 0);
+        for (uint32_t k = 0; k < own.count; ++k)
+            is_boundary[k] = own_cells.find(keys[own.first + k])->second;
+        // a candidate is a ghost iff an own cell lies within one cell of its cell
+        std::unordered_map<int64_t, uint8_t> reached; // foreign cell -> within one cell of an own cell (memoised)
+        std::vector<uint32_t> ghost_list;
+        for (uint32_t g : candidates) {
+            auto it = reached.find(keys[g]);
+            if (it == reached.end()) {
+                int64_t c[3];
+                cell_of_key(keys[g], c);
+                bool near = false;
+                for (int dx = -1; dx <= 1 && !near; ++dx)
+                    for (int dy = -1; dy <= 1 && !near; ++dy)
+                        for (int dz = -1; dz <= 1 && !near; ++dz)
+                            near = own_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
+                it = reached.emplace(keys[g], near).first;
+            }
+            if (it->second)
+                ghost_list.push_back(g);
         }
         for (uint32_t j = 0; j < n_joints; ++j) {
             const uint32_t a = joints[j].body_a, b = joints[j].body_b;
-            const bool own_a = a >= own.first && a < own.first + own.count, own_b = b >= own.first && b < own.first + own.count;
+            const bool own_a = a >= own.first && a < own_end, own_b = b >= own.first && b < own_end;
             if (own_a && !own_b) {
-                is_ghost[b] = 1;
+                ghost_list.push_back(b);
                 is_boundary[a - own.first] = 1;
             } else if (own_b && !own_a) {
-                is_ghost[a] = 1;
+                ghost_list.push_back(a);
                 is_boundary[b - own.first] = 1;
             }
         }
-        ghosts.clear();
+        std::sort(ghost_list.begin(), ghost_list.end());
+        ghost_list.erase(std::unique(ghost_list.begin(), ghost_list.end()), ghost_list.end());
+        ghosts.swap(ghost_list);
         boundary.clear();
-        for (uint32_t g = 0; g < n; ++g)
-            if (is_ghost[g])
-                ghosts.push_back(g);
         for (uint32_t k = 0; k < own.count; ++k)
             if (is_boundary[k])
                 boundary.push_back(own.first + k);
+        if (far) {
+            // dilate the nearby foreign cells by two cells; an own body outside that set (and not a boundary body) is far
+            far->assign(own.count, 0);
+            const size_t limit = 20000; // beyond that many foreign cells around the slab the dilation is not worth it: nobody is far
+            if (own.count && foreign_cells.size() <= limit) {
+                std::unordered_set<int64_t> near_cells;
+                near_cells.reserve(foreign_cells.size() * 40 + 16);
+                for (int64_t key : foreign_cells) {
+                    int64_t c[3];
+                    cell_of_key(key, c);
+                    for (int dx = -2; dx <= 2; ++dx)
+                        for (int dy = -2; dy <= 2; ++dy)
+                            for (int dz = -2; dz <= 2; ++dz)
+                                near_cells.insert(cell_key(c[0] + dx, c[1] + dy, c[2] + dz));
+                }
+                for (uint32_t k = 0; k < own.count; ++k)
+                    (*far)[k] = !near_cells.count(keys[own.first + k]) && !is_boundary[k];
+            }
+        }
     }
 };
 
@@ -204,8 +256,9 @@ struct Shard {
     std::vector<uint32_t> owned_sid;
     // plan
     std::vector<uint32_t> local_ids, ghosts, boundary;
+    std::vector<uint8_t> far; // per owned body: more than two cells away from every foreign body (larger travel allowance)
     uint32_t own_slot0 = 0; // local slot of the first owned body (the owned bodies are contiguous in the local order)
-    DevBuf boundary_slots, ghost_slots, ghost_rows, owned_slots, skip_flags, send, recv, snapshot, disp, disp_all, stage_send, stage_recv;
+    DevBuf boundary_slots, ghost_slots, ghost_rows, owned_slots, skip_flags, disp_scale, send, recv, snapshot, disp, disp_all, stage_send, stage_recv;
     double *disp_host = nullptr; // pinned, n_ranks doubles
 };
 
@@ -221,7 +274,8 @@ struct xpbd_multi_world {
     uint32_t n_global = 0, first_global = 0, n_bodies = 0, capacity = 1;
     std::vector<xpbd_joint> joints;
     uint64_t plans = 0;
-    double last_displacement = 0.0;
+    double cell_edge = 0.0;
+    double last_displacement = 0.0; // the largest fraction of its travel allowance any body had used at the last check, times halo_margin
     bool all_local() const { return shards.size() == n_ranks; }
     uint32_t rows_per_rank() const { return capacity; }
 };
@@ -392,9 +446,9 @@ int make_plan(xpbd_multi_world *mw)
     // 3. who mirrors whom
     HaloPlanner planner;
     planner.n = n, planner.w = w, planner.keys = keys.data();
-    planner.index_cells();
     for (Shard &s : mw->shards)
-        planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), s.ghosts, s.boundary);
+        planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), s.ghosts, s.boundary, &s.far);
+    mw->cell_edge = edge;
 
     // 4. the boundary lists of all ranks (ascending global ids) fix the rows of the per-substep all-gather
     std::vector<uint32_t> counts(w);
@@ -503,6 +557,14 @@ int make_plan(xpbd_multi_world *mw)
         for (uint32_t q : ghost_slots)
             skip[q] = 1;
         MW_TRY(upload_vector(s.skip_flags, skip, s.stream));
+        // 1 / allowance^2 per owned body: the displacement check then yields the largest FRACTION of its allowance any body has used
+        std::vector<double> scale(s.own.count);
+        const double near_allow = mw->margin, far_allow = mw->margin + 0.5 * edge;
+        for (uint32_t i = 0; i < s.own.count; ++i) {
+            const double allow = s.far[i] ? far_allow : near_allow;
+            scale[i] = 1.0 / (allow * allow);
+        }
+        MW_TRY(upload_vector(s.disp_scale, scale, s.stream));
         MW_HIP_TRY(s.send.reserve((size_t)rows * kDyn * 8));
         MW_HIP_TRY(s.recv.reserve((size_t)w * rows * kDyn * 8));
         MW_HIP_TRY(hipMemsetAsync(s.send.ptr, 0, (size_t)rows * kDyn * 8, s.stream));
@@ -535,13 +597,16 @@ int fetch_owned(xpbd_multi_world *mw)
     return XPBD_OK;
 }
 
-// Largest distance any owned body of any rank has travelled since the plan (metres), agreed on by all ranks.
+// Largest fraction of its travel allowance any owned body of any rank has used since the plan, agreed on by all ranks and
+// expressed in margin-equivalent metres (x halo_margin): a body next to a shard boundary may travel halo_margin, one more
+// than two cells away from every foreign body halo_margin + half a cell edge (HaloPlanner::plan_rank).
 int measure_displacement(xpbd_multi_world *mw, double *out)
 {
     for (Shard &s : mw->shards) {
         MW_TRY(bind(s));
         MW_HIP_TRY(hipMemsetAsync(s.disp.ptr, 0, 8, s.stream));
-        if (int rc = xpbd_world_max_displacement2(s.world, s.owned_slots.as<uint32_t>(), s.own.count, s.snapshot.as<double>(), s.disp.as<double>()))
+        if (int rc = xpbd_world_max_displacement2(s.world, s.owned_slots.as<uint32_t>(), s.own.count, s.snapshot.as<double>(), s.disp_scale.as<double>(),
+                                                  s.disp.as<double>()))
             return rc;
     }
     MW_TRY(all_gather_device(mw, 8, [](Shard &s) { return s.disp.ptr; }, [](Shard &s) { return s.disp_all.ptr; })); // 8 bytes per rank
@@ -553,7 +618,7 @@ int measure_displacement(xpbd_multi_world *mw, double *out)
         for (uint32_t r = 0; r < mw->n_ranks; ++r)
             worst = std::max(worst, s.disp_host[r]);
     }
-    *out = std::sqrt(worst);
+    *out = std::sqrt(worst) * mw->margin; // "margin-equivalent" metres: halo_margin means the allowance is used up
     return XPBD_OK;
 }
 
@@ -567,7 +632,7 @@ void destroy(xpbd_multi_world *mw)
             (void)hipStreamSynchronize(s.stream);
         if (s.comm && mw->rccl)
             (void)mw->rccl->CommDestroy(s.comm);
-        for (DevBuf *b : {&s.boundary_slots, &s.ghost_slots, &s.ghost_rows, &s.owned_slots, &s.skip_flags, &s.send, &s.recv, &s.snapshot, &s.disp, &s.disp_all, &s.stage_send, &s.stage_recv})
+        for (DevBuf *b : {&s.boundary_slots, &s.ghost_slots, &s.ghost_rows, &s.owned_slots, &s.skip_flags, &s.disp_scale, &s.send, &s.recv, &s.snapshot, &s.disp, &s.disp_all, &s.stage_send, &s.stage_recv})
             b->release();
         if (s.disp_host)
             (void)hipHostFree(s.disp_host);
@@ -797,8 +862,9 @@ int xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps)
     if (!mw->planned)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_step: no bodies uploaded");
     if (mw->violated)
-        return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body has travelled %.3g m since the halos were planned, beyond halo_margin %.3g m: "
-                                      "remote contacts may have been missed -- call xpbd_multi_world_replan (and re-plan more often or raise the margin)",
+        return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body has used up its travel allowance since the halos were planned (%.3g m in "
+                                      "margin-equivalent metres, halo_margin %.3g m): remote contacts may have been missed -- call "
+                                      "xpbd_multi_world_replan (and re-plan more often or raise the margin)",
                          mw->last_displacement, mw->margin);
     // halo validity, agreed on by all ranks, before anything is stepped
     if (mw->n_ranks > 1) {
@@ -807,8 +873,9 @@ int xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps)
         mw->last_displacement = moved;
         if (!(moved <= mw->margin)) {
             mw->violated = true;
-            return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body has travelled %.3g m since the halos were planned, beyond halo_margin %.3g m: "
-                                          "remote contacts may have been missed in the last frame -- call xpbd_multi_world_replan",
+            return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body has used up its travel allowance since the halos were planned (%.3g m in "
+                                          "margin-equivalent metres, beyond halo_margin %.3g m): remote contacts may have been missed in the "
+                                          "last frame -- call xpbd_multi_world_replan",
                              moved, mw->margin);
         }
         if ((mw->flags & XPBD_MULTI_AUTO_REPLAN) && moved > 0.5 * mw->margin)
@@ -925,7 +992,6 @@ int xpbd_halo_plan(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks
         return set_error(XPBD_E_INVALID, "xpbd_halo_plan: bad argument");
     HaloPlanner planner;
     planner.n = n_global, planner.w = n_ranks, planner.keys = cell_keys;
-    planner.index_cells();
     std::vector<uint32_t> g, b;
     planner.plan_rank(rank, joints, n_joints, g, b);
     *n_ghosts = (uint32_t)g.size(), *n_boundary = (uint32_t)b.size();
@@ -933,6 +999,22 @@ int xpbd_halo_plan(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks
         return set_error(XPBD_E_CAPACITY, "xpbd_halo_plan: %zu ghosts, %zu boundary bodies, capacity %u", g.size(), b.size(), cap);
     std::copy(g.begin(), g.end(), ghosts);
     std::copy(b.begin(), b.end(), boundary);
+    return XPBD_OK;
+}
+
+int xpbd_halo_plan_far(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, uint8_t *far, uint32_t cap, uint32_t *n_owned)
+{
+    if (!cell_keys || !n_owned || n_ranks == 0 || n_ranks > 64 || rank >= n_ranks || (cap && !far))
+        return set_error(XPBD_E_INVALID, "xpbd_halo_plan_far: bad argument");
+    HaloPlanner planner;
+    planner.n = n_global, planner.w = n_ranks, planner.keys = cell_keys;
+    std::vector<uint32_t> g, b;
+    std::vector<uint8_t> f;
+    planner.plan_rank(rank, nullptr, 0, g, b, &f);
+    *n_owned = (uint32_t)f.size();
+    if (f.size() > cap)
+        return set_error(XPBD_E_CAPACITY, "xpbd_halo_plan_far: %zu owned bodies, capacity %u", f.size(), cap);
+    std::copy(f.begin(), f.end(), far);
     return XPBD_OK;
 }
 

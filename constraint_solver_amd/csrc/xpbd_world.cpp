@@ -1153,13 +1153,14 @@ int xpbd_world_snapshot_positions(xpbd_world *w, const uint32_t *dev_indices, ui
     return XPBD_OK;
 }
 
-int xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_snapshot, double *dev_max)
+int xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_snapshot, const double *dev_scale,
+                                 double *dev_max)
 {
     if (!w || !dev_max || (n && (!dev_indices || !dev_snapshot)))
         return fail(XPBD_E_INVALID, "xpbd_world_max_displacement2: NULL argument");
     if (int rc = bind_device(w))
         return rc;
-    XPBD_HIP_TRY(xpbd::launch_max_displacement2(w->arrays(), dev_indices, n, dev_snapshot, dev_max, w->stream));
+    XPBD_HIP_TRY(xpbd::launch_max_displacement2(w->arrays(), dev_indices, n, dev_snapshot, dev_scale, dev_max, w->stream));
     return XPBD_OK;
 }
 

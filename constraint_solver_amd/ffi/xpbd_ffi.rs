@@ -184,7 +184,7 @@ extern "C" {
     pub fn xpbd_world_download_neighbours(w: *mut XpbdWorld, offsets: *mut u32, neighbours: *mut u32, cap: u32) -> c_int;
     pub fn xpbd_world_set_joints(w: *mut XpbdWorld, joints: *const XpbdJoint, n_joints: u32) -> c_int;
     pub fn xpbd_world_snapshot_positions(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *mut f64) -> c_int;
-    pub fn xpbd_world_max_displacement2(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *const f64, dev_max: *mut f64) -> c_int;
+    pub fn xpbd_world_max_displacement2(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *const f64, dev_scale: *const f64, dev_max: *mut f64) -> c_int;
     // ---- extension: the multi-GPU world (one call per frame; the library owns streams, RCCL communicators and the halo plan) ----
     pub fn xpbd_comm_unique_id(id: *mut u8) -> c_int;
     pub fn xpbd_comm_library() -> *const c_char;
@@ -201,6 +201,7 @@ extern "C" {
     pub fn xpbd_multi_world_halo_stats(mw: *mut XpbdMultiWorld, out: *mut u64, max_displacement: *mut f64) -> c_int;
     pub fn xpbd_multi_world_contact_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int;
     pub fn xpbd_halo_cell_key(centre: *const f64, cell_edge: f64) -> i64;
+    pub fn xpbd_halo_plan_far(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, far: *mut u8, cap: u32, n_owned: *mut u32) -> c_int;
     pub fn xpbd_halo_plan(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint, n_joints: u32,
                           ghosts: *mut u32, n_ghosts: *mut u32, boundary: *mut u32, n_boundary: *mut u32, cap: u32) -> c_int;
     pub fn xpbd_world_contacts_begin(w: *mut XpbdWorld, dt: f64) -> c_int;

@@ -285,10 +285,13 @@ int  xpbd_world_import_dynamic_rows(xpbd_world *w, const uint32_t *dev_indices, 
                                     const double *dev_buf);
 
 /* Halo validity for hosts that run their own exchange loop: dev_snapshot[3k..3k+2] = position of body dev_indices[k] (at
- * plan time), and later *dev_max = max(*dev_max, max_k |position_k - snapshot_k|^2) -- the largest squared distance any
- * listed body has travelled (a NaN position counts as +inf).  Device pointers; asynchronous on the world's stream. */
+ * plan time), and later *dev_max = max(*dev_max, max_k scale_k * |position_k - snapshot_k|^2) -- the largest squared distance
+ * any listed body has travelled (a NaN position counts as +inf); dev_scale is optional (NULL: 1), e.g. 1 / allowance_k^2,
+ * which makes the result the largest fraction of its allowance any body has used.  Device pointers; asynchronous on the
+ * world's stream. */
 int  xpbd_world_snapshot_positions(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, double *dev_snapshot);
-int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_snapshot, double *dev_max);
+int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, uint32_t n, const double *dev_snapshot,
+                                  const double *dev_scale, double *dev_max);
 
 /* ---------------------------------------------------------------------------
  * Multi-GPU world (EXTENSION): the caller is still World::integrate (src/world.rs:34-43), now over an N-body
@@ -299,8 +302,9 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
  * bodies within reach, and after EVERY substep the boundary bodies' 13 dynamic doubles travel in ONE all-gather (RCCL over
  * xGMI; XPBD_TRANSPORT_LOCAL = peer copies inside one process, also the single-GPU rehearsal with several shards on one
  * device).  The library builds the halo plan itself (no rank holds the global scene) and checks once per frame, over all
- * ranks, how far any body has travelled since: beyond halo_margin the step FAILS with XPBD_E_HALO rather than lose remote
- * contacts silently; XPBD_MULTI_AUTO_REPLAN re-plans at half the margin.  Result: bit-identical to one xpbd_world over
+ * ranks, how much of its travel allowance any body has used since (halo_margin next to a shard boundary, halo_margin + half
+ * a cell edge for a body more than two cells away from every foreign one): beyond it the step FAILS with XPBD_E_HALO rather
+ * than lose remote contacts silently; XPBD_MULTI_AUTO_REPLAN re-plans at half the allowance.  Result: bit-identical to one xpbd_world over
  * the same bodies in the same order.
  * ------------------------------------------------------------------------- */
 #define XPBD_COMM_ID_BYTES 128u         /* sizeof(ncclUniqueId) */
@@ -347,13 +351,18 @@ int  xpbd_multi_world_replan(xpbd_multi_world *mw);                             
 int  xpbd_multi_world_synchronize(xpbd_multi_world *mw);
 int  xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n);     /* the owned bodies, global order */
 /* out = {bodies of the world, owned here, ghosts here, boundary bodies here, rows per rank of the all-gather, plans made};
- * *max_displacement (optional) = the largest distance any body had travelled at the last check (metres). */
+ * *max_displacement (optional) = the largest fraction of its travel allowance any body had used at the last check, in
+ * margin-equivalent metres (x halo_margin). */
 int  xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *max_displacement);
 int  xpbd_multi_world_contact_stats(xpbd_multi_world *mw, uint64_t out[3]);             /* sums of xpbd_world_contact_stats */
 /* Diagnostics, host only (no device needed): the grid cell key of a bounding-sphere centre, and one rank's halo plan from
  * the cell keys of all bodies (ascending ghost ids: the remote bodies it mirrors; ascending boundary ids: its own bodies
  * that others mirror) exactly as xpbd_multi_world_upload computes it. */
 int64_t xpbd_halo_cell_key(const double centre[3], double cell_edge);
+/* ... and which of the rank's own bodies (in index order) the plan classes as FAR: no foreign body within two cells, so
+ * they may travel halo_margin + half a cell edge before the halos must be re-planned (the others halo_margin). */
+int  xpbd_halo_plan_far(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, uint8_t *far, uint32_t cap,
+                        uint32_t *n_owned);
 int  xpbd_halo_plan(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, const xpbd_joint *joints,
                     uint32_t n_joints, uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary, uint32_t *n_boundary, uint32_t cap);
 

@@ -81,3 +81,31 @@ def test_native_plan_is_conservative_and_symmetric():
         mirrored[ghosts] = True
         boundaries.append(boundary)
     assert np.array_equal(np.nonzero(mirrored)[0], np.sort(np.concatenate(boundaries)))
+
+
+@pytest.mark.parametrize("layout", ["cloud", "slabs"])
+def test_far_bodies_are_more_than_two_cells_from_every_foreign_body(layout):
+    """The larger travel allowance (halo_margin + half a cell edge) is only safe for a body with NO foreign body within two
+    cells at plan time: checked by brute force; in a slab layout most interior bodies do get it."""
+    rng = np.random.default_rng(11)
+    n, world_size, edge = 800, (2 if layout == "slabs" else 4), (0.8 if layout == "slabs" else 1.7)
+    centre = rng.uniform(0, 16, (n, 3))
+    if layout == "slabs":
+        centre = centre[np.argsort(centre[:, 1])]                   # index ranges = slabs along y
+    keys = np.array([capi.halo_cell_key(c, edge) for c in centre], dtype=np.int64)
+    cell = np.floor(centre / edge).astype(np.int64)
+    base, extra = divmod(n, world_size)
+    n_far = 0
+    for rank in range(world_size):
+        first = rank * base + min(rank, extra)
+        count = base + (1 if rank < extra else 0)
+        far = capi.halo_plan_far(keys, world_size, rank)
+        assert len(far) == count
+        foreign = np.ones(n, dtype=bool)
+        foreign[first:first + count] = False
+        for k in np.nonzero(far)[0]:
+            gap = np.abs(cell[foreign] - cell[first + k]).max(axis=1)
+            assert gap.min() >= 3
+        n_far += int(far.sum())
+    if layout == "slabs":
+        assert n_far > 0.3 * n
