@@ -200,3 +200,39 @@ dist.destroy_process_group()
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["same"] and res["sum"] == 4.0 and res["lib"]
     print("RCCL bound from", res["lib"])
+
+
+def test_multi_world_edge_cases():
+    """More ranks than bodies (empty shards), a one-body world, a world without any contact, re-uploading a different scene
+    into the same multi world, and NaN bodies (which count as having outrun every margin)."""
+    kind = capi.SCENE_BOXES_DROP
+    bodies, sid = line_scene(capi, kind, 3, 5, 1.3)
+    with capi.MultiWorld(4, devices=[0] * 4, transport=capi.TRANSPORT_LOCAL, auto_replan=True) as mw:
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.upload(bodies, sid, 0, 3)                                   # ranks 0..2 own one body each, rank 3 none
+        for _ in range(20):
+            mw.step(DT, 5)
+        got = mw.download()
+        one, _ = single(bodies, sid, kind, 20, 5)
+        assert bits_equal(got, one)
+        mw.upload(bodies[:1], sid[:1], 0, 1)                           # a one-body world
+        mw.step(DT, 5)
+        one, _ = single(bodies[:1], sid[:1], kind, 1, 5)
+        assert bits_equal(mw.download(), one)
+        big, big_sid = line_scene(capi, kind, 90, 6, 3.0)              # 3 m pitch: nobody ever touches anybody
+        mw.upload(big, big_sid, 0, 90)
+        for _ in range(10):
+            mw.step(DT, 5)
+        one, stats = single(big, big_sid, kind, 10, 5)
+        assert stats[1] == 0 and bits_equal(mw.download(), one)
+        verts, off = capi.scene_shapes(kind)                           # ... which is the reference path itself
+        want = big
+        for _ in range(10):
+            want, _ = ob.step_bodies(want, big_sid, verts, off, DT, 5)
+        assert bits_equal(one, want)
+        bad = big.copy()
+        bad[7, 31] = np.nan
+        mw.upload(bad, big_sid, 0, 90)                                 # the plan itself copes (NaN cells are clamped) ...
+        with pytest.raises(capi.XpbdError) as e:                       # ... but a NaN position has left every margin
+            mw.step(DT, 5)
+        assert e.value.code == capi.E_HALO
