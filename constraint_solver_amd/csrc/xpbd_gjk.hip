@@ -146,7 +146,8 @@ struct Face {
 };
 
 // Face (i0, i1, i2) of the polytope with its normal turned away from the origin (which is inside).
-__device__ __forceinline__ Face make_face(const GjkLds &s, uint32_t i0, uint32_t i1, uint32_t i2)
+template <class S>
+__device__ __forceinline__ Face make_face(const S &s, uint32_t i0, uint32_t i1, uint32_t i2)
 {
     Face f;
     const Vec3 p0 = ld3(s.vw, i0);
@@ -168,7 +169,8 @@ __device__ __forceinline__ Face make_face(const GjkLds &s, uint32_t i0, uint32_t
     return f;
 }
 
-__device__ __forceinline__ void store_face(GjkLds &s, uint32_t slot, const Face &f)
+template <class S>
+__device__ __forceinline__ void store_face(S &s, uint32_t slot, const Face &f)
 {
     s.fi[slot][0] = f.i0, s.fi[slot][1] = f.i1, s.fi[slot][2] = f.i2;
     st3(s.fn, slot, f.n);
@@ -550,6 +552,287 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
     finish(1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// EPA by a GROUP of L lanes (L = 16: four hits per wave) for shapes of at most kSubVerts vertices.  A hit of the wave-per-hit
+// kernel above spends ~20 k cycles on ~900 VALU instructions: it is a chain of LDS round trips, reductions and fences, and
+// what bounds the kernel is how many hits a CU has in flight (11 with one wave and 13.8 KB of LDS per hit).  A group keeps
+// a polytope of at most kSubPolyVerts vertices / kSubPolyFaces faces (F = 2 V - 4) in 4.3 KB, so a CU holds four times as
+// many hits.  Face f belongs to lane f % L; with at most 64 faces every per-face flag of an iteration (visible, horizon
+// edge e) is one bit of a 64-bit mask assembled from per-round ballots, and the canonical slots of the sequential oracle
+// -- surviving faces keep their order, new faces follow in (visible face, edge) order -- are popcounts of those masks.
+// Same arithmetic per face and the same order as epa_pair, so the same bits.  A hit that would outgrow the small polytope
+// is not finished here: it goes to the overflow list and the wave-per-hit kernel redoes it from its simplex.
+constexpr uint32_t kSubVerts = 16;      // shape vertices per body
+#ifndef XPBD_EPA_SUB_POLY_VERTS
+#define XPBD_EPA_SUB_POLY_VERTS 20      // 4 + 16 expansions (a build with 6 sends most hits through the overflow path: used to test it)
+#endif
+constexpr uint32_t kSubPolyVerts = XPBD_EPA_SUB_POLY_VERTS;
+constexpr uint32_t kSubPolyFaces = 2 * kSubPolyVerts - 4; // Euler: a closed triangulated polytope with V vertices has 2 V - 4 faces
+
+struct EpaSubLds : GjkVertsT<kSubVerts> {
+    double vw[kSubPolyVerts][3], va[kSubPolyVerts][3], vb[kSubPolyVerts][3];
+    uint32_t fi[kSubPolyFaces][3];
+    double fn[kSubPolyFaces][3];
+    double fd[kSubPolyFaces];
+    uint8_t ve[kSubPolyVerts][kSubPolyVerts + 4];
+};
+
+template <uint32_t L>
+__device__ __forceinline__ unsigned long long group_ballot(bool flag)
+{
+    const unsigned long long wave_mask = __ballot(flag);
+    const uint32_t first = (threadIdx.x & 63u) / L * L; // the block is one wave
+    return L == 64 ? wave_mask : (wave_mask >> first) & ((1ull << (L & 63u)) - 1ull);
+}
+
+// returns false when the hit outgrew the small polytope (nothing has been written for it then)
+template <uint32_t L>
+__device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
+                                             const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
+                                             GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint32_t lane)
+{
+    static_assert(kSubPolyFaces <= 64 && L * 4 >= kSubPolyFaces, "face flags live in one 64-bit mask; at most four faces per lane");
+    constexpr uint32_t R = (kSubPolyFaces + L - 1) / L; // faces per lane (rounds)
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
+    const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
+    const ShapeDesc da = t.desc[b.shape_id[ia]], db = t.desc[b.shape_id[ib]];
+    const uint32_t na = da.n_verts, nb = db.n_verts;
+    GjkResult *r = out ? out + p : nullptr;
+    ContactManifold *mf = manifolds ? manifolds + p : nullptr;
+    uint32_t epa_iters = 0;
+    auto finish = [&](int32_t st) {
+        if (lane == 0) {
+            if (r) {
+                r->status = st;
+                r->epa_iterations = epa_iters;
+            }
+            if (mf && st != 1)
+                mf->n_points = 0;
+        }
+    };
+    // first / lowest face with the smallest plane distance, over the group
+    auto closest = [&](uint32_t nf, double *dist_out) {
+        double bd = DBL_MAX;
+        uint32_t bi = kNone;
+        for (uint32_t f = lane; f < nf; f += L)
+            if (s.fd[f] < bd) {
+                bd = s.fd[f];
+                bi = f;
+            }
+        for (uint32_t off = L / 2; off; off >>= 1) {
+            const double od = __shfl_xor(bd, off, 64);
+            const uint32_t oi = __shfl_xor(bi, off, 64);
+            if (od < bd || (od == bd && oi < bi)) {
+                bd = od;
+                bi = oi;
+            }
+        }
+        *dist_out = bd;
+        return bi;
+    };
+
+    stage_world_vertices(s, t, da, db, fa, fb, lane, L);
+    __syncthreads();
+    if (lane < 4) {
+        const uint32_t va = (uint32_t)(seed >> (8 * lane)) & 0xFFu, vb = (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu;
+        const Vec3 a = ld3(s.wa, va), bb = ld3(s.wb, vb);
+        st3(s.vw, lane, a - bb);
+        st3(s.va, lane, a);
+        st3(s.vb, lane, bb);
+    }
+    __syncthreads();
+    uint32_t nv = 4, nf = 4;
+    {
+        bool bad = false;
+        if (lane < 4) {
+            const uint32_t t0 = lane == 3 ? 1u : 0u;
+            const uint32_t t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
+            const uint32_t t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
+            const Face f = make_face(s, t0, t1, t2); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}
+            store_face(s, lane, f);
+            bad = !f.ok;
+        }
+        if (group_ballot<L>(bad)) {
+            finish(2);
+            return true;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t it = 0; it < kMaxEpaIters; ++it) {
+        epa_iters = it + 1;
+        double best_dist;
+        const uint32_t best = closest(nf, &best_dist);
+        const Vec3 bn = ld3(s.fn, best);
+        const MVert pnt = minkowski_support<L>(s, na, nb, bn, lane);
+        if (dot(pnt.w, bn) - best_dist < kEpaTolerance)
+            break;
+        if (nv == kSubPolyVerts)
+            return false; // (epa_pair stops at kMaxEpaVerts: this hit needs the large polytope)
+
+        // visibility of my faces f = lane + L * j; bit f of `vis` for the whole group
+        bool my_vis[R];
+        unsigned long long vis = 0, valid = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            const uint32_t f = lane + L * j;
+            my_vis[j] = f < nf && dot(ld3(s.fn, f), pnt.w - ld3(s.vw, s.fi[f][0])) > 0.0;
+            vis |= group_ballot<L>(my_vis[j]) << (L * j);
+            valid |= group_ballot<L>(f < nf) << (L * j);
+        }
+        // horizon: the visible faces mark their directed edges, every edge of a visible face looks its reverse up, the
+        // marks are cleared again (see epa_pair)
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j)
+            if (my_vis[j]) {
+                const uint32_t f = lane + L * j;
+                for (uint32_t e = 0; e < 3; ++e)
+                    s.ve[s.fi[f][e]][s.fi[f][e == 2 ? 0 : e + 1]] = 1;
+            }
+        __syncthreads();
+        uint32_t hz[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            hz[j] = 0;
+            if (my_vis[j]) {
+                const uint32_t f = lane + L * j;
+                for (uint32_t e = 0; e < 3; ++e)
+                    if (!s.ve[s.fi[f][e == 2 ? 0 : e + 1]][s.fi[f][e]])
+                        hz[j] |= 1u << e;
+            }
+        }
+        __syncthreads();
+        unsigned long long edge_mask[3] = {0, 0, 0}; // bit f: edge e of face f is on the horizon
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            if (my_vis[j]) {
+                const uint32_t f = lane + L * j;
+                for (uint32_t e = 0; e < 3; ++e)
+                    s.ve[s.fi[f][e]][s.fi[f][e == 2 ? 0 : e + 1]] = 0;
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < 3; ++e)
+                edge_mask[e] |= group_ballot<L>((hz[j] >> e) & 1u) << (L * j);
+        }
+        const unsigned long long kept = valid & ~vis;
+        const uint32_t keep = (uint32_t)__popcll(kept);
+        const uint32_t ne = (uint32_t)(__popcll(edge_mask[0]) + __popcll(edge_mask[1]) + __popcll(edge_mask[2]));
+        if (ne == 0)
+            break; // numerical dead end: report the best face found so far (as epa_pair)
+        if (keep + ne > kSubPolyFaces)
+            return false;
+
+        // pull my faces into registers, then rewrite the face table in the canonical order
+        Face mine[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            const uint32_t f = lane + L * j;
+            if (f < nf) {
+                mine[j].i0 = s.fi[f][0], mine[j].i1 = s.fi[f][1], mine[j].i2 = s.fi[f][2];
+                mine[j].n = ld3(s.fn, f);
+                mine[j].dist = s.fd[f];
+            }
+        }
+        if (lane == 0) {
+            st3(s.vw, nv, pnt.w);
+            st3(s.va, nv, pnt.a);
+            st3(s.vb, nv, pnt.b);
+        }
+        __syncthreads();
+        bool bad = false;
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            const uint32_t f = lane + L * j;
+            if (f >= nf)
+                continue;
+            const unsigned long long below = (1ull << f) - 1ull;
+            if (!my_vis[j]) {
+                store_face(s, (uint32_t)__popcll(kept & below), mine[j]);
+                continue;
+            }
+            // my horizon edges come after those of all lower faces, in edge order
+            uint32_t slot = keep + (uint32_t)(__popcll(edge_mask[0] & below) + __popcll(edge_mask[1] & below) + __popcll(edge_mask[2] & below));
+            const uint32_t ea[3] = {mine[j].i0, mine[j].i1, mine[j].i2}, eb[3] = {mine[j].i1, mine[j].i2, mine[j].i0};
+            for (uint32_t e = 0; e < 3; ++e)
+                if (hz[j] & (1u << e)) {
+                    const Face nfce = make_face(s, ea[e], eb[e], nv);
+                    store_face(s, slot++, nfce);
+                    bad |= !nfce.ok;
+                }
+        }
+        nf = keep + ne;
+        ++nv;
+        __syncthreads();
+        if (group_ballot<L>(bad)) {
+            finish(2);
+            return true;
+        }
+    }
+
+    double best_dist;
+    const uint32_t best = closest(nf, &best_dist);
+    if (lane == 0) {
+        const uint32_t i0 = s.fi[best][0], i1 = s.fi[best][1], i2 = s.fi[best][2];
+        const Vec3 nrm = ld3(s.fn, best);
+        const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
+        const Vec3 v0 = ld3(s.vw, i1) - aw, v1 = ld3(s.vw, i2) - aw, v2 = proj - aw;
+        const double d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+        const double denom = d00 * d11 - d01 * d01;
+        const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
+        const Vec3 pa = ld3(s.va, i0) * bu + ld3(s.va, i1) * bv + ld3(s.va, i2) * bw;
+        const Vec3 pb = ld3(s.vb, i0) * bu + ld3(s.vb, i1) * bv + ld3(s.vb, i2) * bw;
+        if (r) {
+            r->depth = best_dist;
+            r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
+            r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
+            r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
+        }
+        if (mf) {
+            mf->n_points = 1;
+            mf->feature = 2; // reference body A, incident body B
+            mf->index_a = mf->index_b = 0;
+            mf->separation = -best_dist;
+            mf->point[0][1][0] = pa.x, mf->point[0][1][1] = pa.y, mf->point[0][1][2] = pa.z; // on the reference body A
+            mf->point[0][0][0] = pb.x, mf->point[0][0][1] = pb.y, mf->point[0][0][2] = pb.z; // on the incident body B
+        }
+    }
+    finish(1);
+    return true;
+}
+
+// Four hits per wave (16 lanes each), grid-stride over the hit list; hits that outgrow the small polytope are appended to
+// `overflow` (one atomic each: rare) for k_epa_pairs.  Block 0 zeroes the counter the NEXT k_gjk_pairs launch appends
+// through -- the overflow pass (launched after this kernel with the same pointer) only zeroes it again.
+template <uint32_t L>
+__global__ void __launch_bounds__(64) k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+                                                      const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
+                                                      ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_count,
+                                                      uint32_t *__restrict__ next_hit_count, const uint32_t *__restrict__ hits,
+                                                      const unsigned long long *__restrict__ seeds, uint32_t *__restrict__ overflow_count,
+                                                      uint32_t *__restrict__ overflow)
+{
+    constexpr uint32_t PW = 64 / L;
+    __shared__ EpaSubLds s_all[PW];
+    EpaSubLds &s = s_all[threadIdx.x / L];
+    const uint32_t lane = threadIdx.x % L;
+    for (uint32_t k = lane; k < sizeof(s.ve) / 4; k += L)
+        reinterpret_cast<uint32_t *>(&s.ve[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t n_hits = *hit_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *next_hit_count = 0;
+    for (uint32_t h = blockIdx.x * PW + threadIdx.x / L; h < n_hits; h += gridDim.x * PW) {
+        const uint32_t p = hits[h];
+        const bool done = epa_pair_sub<L>(s, b, t, frames, pairs, p, seeds[p], out, manifolds, lane);
+        if (!done) {
+            // the marks of the interrupted iteration were cleared before the exits; hand the hit over
+            if (lane == 0)
+                overflow[atomicAdd(overflow_count, 1u)] = p;
+        }
+        __syncthreads(); // the next hit reuses the LDS
+    }
+}
+
 // One wave per block, grid-stride over the hit list of the k_gjk_pairs launch before it.  Block 0 also zeroes the
 // counter the NEXT k_gjk_pairs launch appends through (the two counters alternate, see GjkScratch).
 __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
@@ -574,7 +857,8 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
 
 } // namespace
 
-size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 12 + 8; }
+// seeds (8 bytes per pair), hit list and overflow list (4 bytes per pair each), the overflow counter
+size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 16 + 16; }
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                 uint32_t n_pairs, GjkResult *out, ContactManifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
@@ -610,6 +894,18 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         launch(integral_constant<uint32_t, 32>{}, std::true_type{});
     else
         launch(integral_constant<uint32_t, 32>{}, std::false_type{});
+    if (t.max_verts <= kSubVerts) {
+        // small shapes: four hits per wave; the rare hit that outgrows the small polytope is redone by the wave-per-hit kernel
+        uint32_t *overflow = hits + n_pairs, *overflow_count = overflow + n_pairs;
+        if (hipError_t e = hipMemsetAsync(overflow_count, 0, 4, stream))
+            return e;
+        const uint32_t groups = (n_pairs + 3) / 4;
+        hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
+                           manifolds, count, next, hits, seeds, overflow_count, overflow);
+        hipLaunchKernelGGL(k_epa_pairs, dim3(n_pairs < 256 ? n_pairs : 256), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds,
+                           overflow_count, next, overflow, seeds);
+        return hipGetLastError();
+    }
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
     hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, next, hits,
                        seeds);
