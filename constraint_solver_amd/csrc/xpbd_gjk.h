@@ -22,9 +22,15 @@ struct GjkResult {
 
 constexpr uint32_t kEpaBlocks = 8192;   // grid of the EPA kernel (one wave per block, grid-stride over the hits)
 
-// Device scratch of the two-kernel narrowphase.  `counters`: two uint32, zero when idle; launch k appends its
-// penetrating pairs through counters[k & 1] and its EPA kernel zeroes counters[(k + 1) & 1] for the next launch
-// (all launches of one world are stream-ordered).  `pairs_scratch`: gjk_scratch_bytes(n_pairs) bytes.
+// Device scratch of the two-kernel narrowphase.  The hit list is SEGMENTED: workgroup g of the GJK kernel appends to segment
+// g % kHitSegments through that segment's own counter, each counter on a cache line of its own -- one list behind one
+// counter meant one same-address atomic per wave, which serialise at ~10 ns each: 30 000 waves = the whole 300 us of the
+// kernel, whatever it computed.  `counters`: two sets (launch k appends through set k & 1, its EPA kernel zeroes set
+// (k + 1) & 1 for the next launch; all launches of one world are stream-ordered) of kHitSegments counters,
+// kHitCounterStride uint32 apart, zero when idle: gjk_counter_bytes() bytes.  `pairs_scratch`: gjk_scratch_bytes(n_pairs).
+constexpr uint32_t kHitSegments = 32;
+constexpr uint32_t kHitCounterStride = 32; // uint32: 128 bytes
+constexpr size_t gjk_counter_bytes() { return (size_t)2 * kHitSegments * kHitCounterStride * 4; }
 struct GjkScratch {
     uint32_t *counters;
     void *pairs_scratch;

@@ -51,6 +51,20 @@ struct GjkLds : GjkVerts {
     uint8_t ve[kMaxEpaVerts][kMaxEpaVerts + 4];
 };
 
+#ifdef XPBD_GJK_TIMING
+// Diagnostics build only: cycles spent by the waves of k_gjk_pairs in its phases, summed over waves (lane 0 of each wave).
+__device__ unsigned long long g_gjk_timing[8];
+#define GJK_TICK(slot)                                                                       \
+    do {                                                                                     \
+        const unsigned long long now_ = clock64();                                           \
+        if (threadIdx.x == 0)                                                                \
+            atomicAdd(&g_gjk_timing[slot], now_ - tick_);                                    \
+        tick_ = now_;                                                                        \
+    } while (0)
+#else
+#define GJK_TICK(slot) do { } while (0)
+#endif
+
 struct MVert {
     Vec3 w, a, b;     // w = a - b
     uint32_t ia, ib;  // a = A's world vertex ia, b = B's world vertex ib
@@ -212,6 +226,42 @@ __device__ __forceinline__ void stage_world_vertices(Verts &s, const PolytopeTab
     }
 }
 
+// The shape tables the GJK / EPA kernels read per pair -- descriptor, centroid, bounding radius, vertices -- staged into LDS
+// once per workgroup when the world's tables are small (the usual case: a handful of shapes).  Phase timing of k_gjk_pairs
+// on the settled mixed pile (scripts/gjk_phase_timing.py): the GJK iterations were a fifth of a wave's time, the rest the
+// chain of dependent global loads in front of them (pair -> record and shape id -> descriptor, centroid, radius ->
+// vertices) and the stores behind; with the tables in LDS the chain ends at the shape id.
+constexpr uint32_t kStageShapes = 8, kStageVerts = 64;
+struct StagedTables {
+    double verts[kStageVerts * 3];
+    double centroids[kStageShapes * 3];
+    double radii[kStageShapes];
+    ShapeDesc desc[kStageShapes];
+};
+
+// all lanes of the workgroup; returns the tables to use (pointing into `sh` when staged)
+template <bool STAGED>
+__device__ __forceinline__ PolytopeTables stage_tables(const PolytopeTables &t, StagedTables &sh)
+{
+    if (!STAGED)
+        return t;
+    for (uint32_t k = threadIdx.x; k < 3 * t.total_verts; k += blockDim.x)
+        sh.verts[k] = t.verts[k];
+    for (uint32_t k = threadIdx.x; k < t.n_shapes; k += blockDim.x) {
+        sh.desc[k] = t.desc[k];
+        sh.radii[k] = t.radii[k];
+        for (uint32_t a = 0; a < 3; ++a)
+            sh.centroids[3 * k + a] = t.centroids[3 * k + a];
+    }
+    __syncthreads();
+    PolytopeTables l = t;
+    l.verts = sh.verts;
+    l.centroids = sh.centroids;
+    l.radii = sh.radii;
+    l.desc = sh.desc;
+    return l;
+}
+
 // Vertex indices of the four simplex points: byte k = A's index of point k, byte 4 + k = B's.
 __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const MVert &s1, const MVert &s2, const MVert &s3)
 {
@@ -227,17 +277,22 @@ __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const M
 // list, n_pairs is read from *survivor_count, and block 0 zeroes the counter of the next launch.
 // V: vertex capacity per body of a pair's LDS record (the launcher picks 16 when no shape has more: 768 bytes per pair
 // instead of 1 536, i.e. twice as many waves per CU for a kernel that waits on LDS round trips and shuffles).
-template <uint32_t L, uint32_t V, bool PRETEST>
-__global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+template <uint32_t L, uint32_t V, bool PRETEST, bool STAGED>
+__global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t_global, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                   const uint32_t *__restrict__ survivors, const uint32_t *__restrict__ survivor_count,
                                                   uint32_t *__restrict__ next_survivor_count,
                                                   GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds,
-                                                  uint32_t *__restrict__ hit_count, uint32_t *__restrict__ hits,
+                                                  uint32_t *__restrict__ hit_counts, uint32_t *__restrict__ hits, uint32_t segment_capacity,
                                                   unsigned long long *__restrict__ seeds)
 {
+#ifdef XPBD_GJK_TIMING
+    unsigned long long tick_ = clock64();
+#endif
     constexpr uint32_t PW = 64 / L; // pairs per wave
     __shared__ GjkVertsT<V> s_all[PW];
+    __shared__ StagedTables staged;
+    const PolytopeTables t = stage_tables<STAGED>(t_global, staged);
     GjkVertsT<V> &s = s_all[threadIdx.x / L];
     const uint32_t slot = blockIdx.x * PW + threadIdx.x / L;
     const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
@@ -265,9 +320,11 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
         const double reach = t.radii[sa] + t.radii[sb];
         usable = dot(between, between) < reach * reach;
     }
+    GJK_TICK(0); // input loads + pre-test
     if (usable)
         stage_world_vertices(s, t, da, db, fa, fb, lane, L);
     __syncthreads();
+    GJK_TICK(1); // vertex staging
 
     // status: 0 separated, 1 penetrating (goes to EPA), 2 degenerate; the simplex is identical on every lane of the group
     int32_t status = 0;
@@ -329,6 +386,13 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
         }
     }
 
+    GJK_TICK(2); // the GJK iterations
+#ifdef XPBD_GJK_TIMING
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_gjk_timing[4], 1ull);
+        atomicAdd(&g_gjk_timing[5], (unsigned long long)gjk_iters);
+    }
+#endif
     // verdicts; the wave appends its penetrating pairs to the hit list with ONE atomic
     const bool writer = live && lane == 0;
     if (writer) {
@@ -345,15 +409,17 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     if (hit_mask) {
         const uint32_t leader = (uint32_t)__ffsll((long long)hit_mask) - 1u;
         uint32_t base = 0;
+        const uint32_t segment = blockIdx.x % kHitSegments; // this workgroup's segment of the hit list, with a counter of its own
         if (threadIdx.x == leader)
-            base = atomicAdd(hit_count, (uint32_t)__popcll(hit_mask));
+            base = atomicAdd(hit_counts + segment * kHitCounterStride, (uint32_t)__popcll(hit_mask));
         base = __shfl(base, leader, 64);
         if (hit) {
             const uint32_t slot = base + (uint32_t)__popcll(hit_mask & ((1ull << threadIdx.x) - 1ull));
-            hits[slot] = p;
+            hits[(size_t)segment * segment_capacity + slot] = p;
             seeds[p] = pack_seed(s0, s1, s2, s3);
         }
     }
+    GJK_TICK(3); // verdicts and hit list
 }
 
 // EPA of one penetrating pair by one wave; the polytope starts from the simplex k_gjk_pairs left.
@@ -550,6 +616,40 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         }
     }
     finish(1);
+}
+
+// The segmented hit list as its consumers see it: `prefix` (LDS, n_segments + 1 entries) = exclusive prefix sums of the
+// segment counts; entry h of the concatenation is hits[segment * capacity + (h - prefix[segment])].  First wave of the block
+// fills it (all threads must call: it has a barrier); returns the total.  Also zeroes the NEXT launch's counters (block 0).
+__device__ __forceinline__ uint32_t hit_list_open(uint32_t *prefix, const uint32_t *__restrict__ counts, uint32_t n_segments,
+                                                  uint32_t *__restrict__ next_counts, uint32_t n_next)
+{
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < n_segments; ++k) {
+            prefix[k] = run;
+            run += counts[k * kHitCounterStride];
+        }
+        prefix[n_segments] = run;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n_next)
+        next_counts[threadIdx.x * kHitCounterStride] = 0;
+    __syncthreads();
+    return prefix[n_segments];
+}
+
+__device__ __forceinline__ uint32_t hit_list_entry(const uint32_t *prefix, uint32_t n_segments, const uint32_t *__restrict__ hits,
+                                                   uint32_t capacity, uint32_t h)
+{
+    uint32_t lo = 0, hi = n_segments; // the segment with prefix[seg] <= h < prefix[seg + 1]
+    while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= h)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return hits[(size_t)lo * capacity + (h - prefix[lo])];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -803,26 +903,26 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 // Four hits per wave (16 lanes each), grid-stride over the hit list; hits that outgrow the small polytope are appended to
 // `overflow` (one atomic each: rare) for k_epa_pairs.  Block 0 zeroes the counter the NEXT k_gjk_pairs launch appends
 // through -- the overflow pass (launched after this kernel with the same pointer) only zeroes it again.
-template <uint32_t L>
-__global__ void __launch_bounds__(64) k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
+template <uint32_t L, bool STAGED>
+__global__ void __launch_bounds__(64) k_epa_pairs_sub(BodyArrays b, PolytopeTables t_global, const double *__restrict__ frames,
                                                       const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
-                                                      ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_count,
-                                                      uint32_t *__restrict__ next_hit_count, const uint32_t *__restrict__ hits,
-                                                      const unsigned long long *__restrict__ seeds, uint32_t *__restrict__ overflow_count,
-                                                      uint32_t *__restrict__ overflow)
+                                                      ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
+                                                      uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
+                                                      uint32_t segment_capacity, const unsigned long long *__restrict__ seeds,
+                                                      uint32_t *__restrict__ overflow_count, uint32_t *__restrict__ overflow)
 {
     constexpr uint32_t PW = 64 / L;
     __shared__ EpaSubLds s_all[PW];
+    __shared__ StagedTables staged;
+    const PolytopeTables t = stage_tables<STAGED>(t_global, staged);
     EpaSubLds &s = s_all[threadIdx.x / L];
     const uint32_t lane = threadIdx.x % L;
     for (uint32_t k = lane; k < sizeof(s.ve) / 4; k += L)
         reinterpret_cast<uint32_t *>(&s.ve[0][0])[k] = 0;
-    __syncthreads();
-    const uint32_t n_hits = *hit_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *next_hit_count = 0;
+    __shared__ uint32_t prefix[kHitSegments + 1];
+    const uint32_t n_hits = hit_list_open(prefix, hit_counts, kHitSegments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x * PW + threadIdx.x / L; h < n_hits; h += gridDim.x * PW) {
-        const uint32_t p = hits[h];
+        const uint32_t p = hit_list_entry(prefix, kHitSegments, hits, segment_capacity, h);
         const bool done = epa_pair_sub<L>(s, b, t, frames, pairs, p, seeds[p], out, manifolds, lane);
         if (!done) {
             // the marks of the interrupted iteration were cleared before the exits; hand the hit over
@@ -833,23 +933,22 @@ __global__ void __launch_bounds__(64) k_epa_pairs_sub(BodyArrays b, PolytopeTabl
     }
 }
 
-// One wave per block, grid-stride over the hit list of the k_gjk_pairs launch before it.  Block 0 also zeroes the
-// counter the NEXT k_gjk_pairs launch appends through (the two counters alternate, see GjkScratch).
+// One wave per block, grid-stride over a hit list (n_segments segments of `segment_capacity` entries; the overflow list of
+// k_epa_pairs_sub is one segment).  Block 0 also zeroes the counters the NEXT k_gjk_pairs launch appends through (the two
+// sets alternate, see GjkScratch).
 __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                   const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
-                                                  ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_count,
-                                                  uint32_t *__restrict__ next_hit_count, const uint32_t *__restrict__ hits,
-                                                  const unsigned long long *__restrict__ seeds)
+                                                  ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
+                                                  uint32_t n_segments, uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
+                                                  uint32_t segment_capacity, const unsigned long long *__restrict__ seeds)
 {
     __shared__ GjkLds s;
     for (uint32_t k = threadIdx.x; k < sizeof(s.ve) / 4; k += 64)
         reinterpret_cast<uint32_t *>(&s.ve[0][0])[k] = 0;
-    __syncthreads();
-    const uint32_t n_hits = *hit_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *next_hit_count = 0;
+    __shared__ uint32_t prefix[kHitSegments + 1];
+    const uint32_t n_hits = hit_list_open(prefix, hit_counts, n_segments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x; h < n_hits; h += gridDim.x) {
-        const uint32_t p = hits[h];
+        const uint32_t p = hit_list_entry(prefix, n_segments, hits, segment_capacity, h);
         epa_pair(s, b, t, frames, pairs, p, seeds[p], out, manifolds, threadIdx.x);
         __syncthreads(); // the next hit reuses the LDS
     }
@@ -857,8 +956,23 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
 
 } // namespace
 
-// seeds (8 bytes per pair), hit list and overflow list (4 bytes per pair each), the overflow counter
-size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 16 + 16; }
+// seeds (8 bytes per pair), the segmented hit list (4 bytes per pair + one wave's worth of slack per segment), the overflow
+// list (4 bytes per pair) and its counter
+#ifdef XPBD_GJK_TIMING
+extern "C" int xpbd_debug_gjk_timing(unsigned long long out[8], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gjk_timing), sizeof(unsigned long long) * 8) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_gjk_timing), zero, sizeof zero) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
+
+size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 16 + (size_t)kHitSegments * 64 * 4 + 16; }
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                 uint32_t n_pairs, GjkResult *out, ContactManifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
@@ -868,7 +982,8 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         return hipSuccess;
     unsigned long long *seeds = static_cast<unsigned long long *>(scratch.pairs_scratch);
     uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + n_pairs);
-    uint32_t *count = scratch.counters + (scratch.calls & 1u), *next = scratch.counters + ((scratch.calls + 1u) & 1u);
+    uint32_t *count = scratch.counters + (scratch.calls & 1u) * kHitSegments * kHitCounterStride;
+    uint32_t *next = scratch.counters + ((scratch.calls + 1u) & 1u) * kHitSegments * kHitCounterStride;
     ++scratch.calls;
     const uint32_t *survivors = nullptr;
     uint32_t *survivor_count = nullptr, *next_survivor_count = nullptr;
@@ -878,10 +993,19 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         survivors = list->survivors;
         sphere_pretest = false; // the survivors have passed it
     }
+    const bool staged = t.n_shapes <= kStageShapes && t.total_verts <= kStageVerts;
+    uint32_t segment_capacity = 0;
     auto launch = [&](auto lanes, auto pretest) {
         constexpr uint32_t L = decltype(lanes)::value, V = L == 32 ? kMaxV : 16;
-        hipLaunchKernelGGL((k_gjk_pairs<L, V, decltype(pretest)::value>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
-                           frames, pairs, n_pairs, survivors, survivor_count, next_survivor_count, out, manifolds, count, hits, seeds);
+        constexpr bool P = decltype(pretest)::value;
+        const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
+        segment_capacity = (grid.x + kHitSegments - 1) / kHitSegments * (64 / L); // what the workgroups of one segment can append
+        if (staged)
+            hipLaunchKernelGGL((k_gjk_pairs<L, V, P, true>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds);
+        else
+            hipLaunchKernelGGL((k_gjk_pairs<L, V, P, false>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds);
     };
     using std::integral_constant;
     // lanes per pair: XPBD_GJK_SMALL_LANES for shapes of at most 16 vertices (the simplex logic is replicated on every
@@ -896,19 +1020,23 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         launch(integral_constant<uint32_t, 32>{}, std::false_type{});
     if (t.max_verts <= kSubVerts) {
         // small shapes: four hits per wave; the rare hit that outgrows the small polytope is redone by the wave-per-hit kernel
-        uint32_t *overflow = hits + n_pairs, *overflow_count = overflow + n_pairs;
+        uint32_t *overflow = hits + n_pairs + kHitSegments * 64, *overflow_count = overflow + n_pairs;
         if (hipError_t e = hipMemsetAsync(overflow_count, 0, 4, stream))
             return e;
         const uint32_t groups = (n_pairs + 3) / 4;
-        hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
-                           manifolds, count, next, hits, seeds, overflow_count, overflow);
+        if (staged)
+            hipLaunchKernelGGL((k_epa_pairs_sub<16, true>), dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames,
+                               pairs, out, manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+        else
+            hipLaunchKernelGGL((k_epa_pairs_sub<16, false>), dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames,
+                               pairs, out, manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
         hipLaunchKernelGGL(k_epa_pairs, dim3(n_pairs < 256 ? n_pairs : 256), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds,
-                           overflow_count, next, overflow, seeds);
+                           overflow_count, 1u, next, overflow, n_pairs, seeds);
         return hipGetLastError();
     }
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
-    hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, next, hits,
-                       seeds);
+    hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, kHitSegments, next, hits,
+                       segment_capacity, seeds);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ struct PolytopeTables {
     const double *edge_dirs;     // [total_dirs][3] shape-local direction v[e.1] - v[e.0] of the first edge with it
     const uint32_t *edge_dir_id; // [total_edges] shape-local index of every edge's direction
     uint32_t n_shapes;
+    uint32_t total_verts;        // vertices of all shapes together
     uint32_t max_verts, max_faces, max_face_verts; // over all shapes: the narrowphase launchers pick their sub-wave width by them
     // Mixed worlds: shapes of at most 8 vertices and 8 faces are the SMALL class (0), the others class 1; a pair's class is
     // the larger of its bodies'.  With both classes present the two-pass SAT keeps one survivor list per class and runs the

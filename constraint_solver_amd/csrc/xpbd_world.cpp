@@ -129,7 +129,7 @@ struct xpbd_world {
         return xpbd::PolytopeTables{shape_verts.as<double>(), planes.as<double>(), centroids.as<double>(),
                                     shape_desc.as<xpbd::ShapeDesc>(), face_start.as<uint32_t>(),
                                     face_verts.as<uint32_t>(), edges.as<uint32_t>(), shape_radii.as<double>(),
-                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, max_verts, max_faces, max_face_verts,
+                                    edge_dirs.as<double>(), edge_dir_id.as<uint32_t>(), n_shapes, total_verts, max_verts, max_faces, max_face_verts,
                                     shape_class.as<uint8_t>(), two_classes, small_max_face_verts};
     }
 
@@ -227,8 +227,8 @@ uint32_t next_pow2(uint32_t v)
 int ensure_gjk_scratch(xpbd_world *w, uint32_t n_pairs)
 {
     if (!w->gjk_counters.ptr) {
-        XPBD_HIP_TRY(w->gjk_counters.reserve(8));
-        XPBD_HIP_TRY(hipMemsetAsync(w->gjk_counters.ptr, 0, 8, w->stream));
+        XPBD_HIP_TRY(w->gjk_counters.reserve(xpbd::gjk_counter_bytes()));
+        XPBD_HIP_TRY(hipMemsetAsync(w->gjk_counters.ptr, 0, xpbd::gjk_counter_bytes(), w->stream));
         w->gjk_scratch.calls = 0;
     }
     XPBD_HIP_TRY(w->gjk_pairs_scratch.reserve(xpbd::gjk_scratch_bytes(n_pairs ? n_pairs : 1)));
