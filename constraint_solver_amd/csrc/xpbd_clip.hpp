@@ -1,0 +1,188 @@
+// xpbd_clip.hpp -- the face contact of the body-body contact EXTENSION, shared by the SAT (xpbd_pairs.hip) and the
+// GJK + EPA narrowphase (xpbd_gjk.hip): incident face choice, Sutherland-Hodgman clipping with one polygon vertex per
+// lane, and the small LDS / reduction helpers both files use.  Device-only; the block is ONE wave everywhere this is used.
+//
+// Reference lines the conventions come from (the reference's `sat` is an uncalled stub, parity UNPINNED; the checker is
+// face_contact of oracle/xpbd_pairs_oracle.c):
+//   reference plane = frames.0 * polytopes.0.plane(face)          src/collision.rs:66
+//   incident face   = least normal . ref_normal, first minimum     src/collision.rs:76-85
+//   partner point   = Plane::project                               src/geometry.rs:45-47
+#pragma once
+#include <cfloat>
+
+#include "xpbd_device.hpp"
+#include "xpbd_pairs.h"
+
+namespace xpbd {
+
+__device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
+__device__ __forceinline__ void st3(double (*a)[3], uint32_t k, Vec3 v)
+{
+    a[k][0] = v.x;
+    a[k][1] = v.y;
+    a[k][2] = v.z;
+}
+
+// Key whose signed-integer order is IEEE totalOrder (Rust f64::total_cmp).
+__device__ __forceinline__ long long total_key(double v)
+{
+    const long long i = __double_as_longlong(v);
+    return i ^ (long long)((unsigned long long)(i >> 63) >> 1);
+}
+
+// (value, index) reductions over `width` consecutive lanes (a power of two; xor offsets < width stay inside
+// the aligned group).
+__device__ __forceinline__ void reduce_max_first(double &v, uint32_t &idx, uint32_t width)
+{
+    for (uint32_t off = width >> 1; off; off >>= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const uint32_t oi = __shfl_xor(idx, off, 64);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+__device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint32_t width)
+{
+    for (uint32_t off = width >> 1; off; off >>= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const uint32_t oi = __shfl_xor(idx, off, 64);
+        if (ov < v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+// The bits of a wave-wide ballot that belong to the calling lane's group of L lanes, moved down to bit 0.
+template <uint32_t L>
+__device__ __forceinline__ uint64_t group_bits(unsigned long long wave_mask)
+{
+    const uint32_t first = (threadIdx.x & 63u) / L * L; // the block is one wave
+    return L == 64 ? wave_mask : (wave_mask >> first) & ((1ull << (L & 63u)) - 1ull);
+}
+
+// One contact point into either result layout.
+__device__ __forceinline__ void set_point(Manifold &m, uint32_t k, Vec3 inc, Vec3 ref)
+{
+    m.p_inc[k][0] = inc.x, m.p_inc[k][1] = inc.y, m.p_inc[k][2] = inc.z;
+    m.p_ref[k][0] = ref.x, m.p_ref[k][1] = ref.y, m.p_ref[k][2] = ref.z;
+}
+__device__ __forceinline__ void set_point(ContactManifold &m, uint32_t k, Vec3 inc, Vec3 ref)
+{
+    m.point[k][0][0] = inc.x, m.point[k][0][1] = inc.y, m.point[k][0][2] = inc.z;
+    m.point[k][1][0] = ref.x, m.point[k][1][1] = ref.y, m.point[k][1][2] = ref.z;
+}
+
+// Face contact of one pair by a group of L lanes: reference face `ref_face` of body R (frame fr, shape dr, world-space
+// vertices world_r), incident body I (fi, di, world_i).  Writes the contact points of *m and returns their number;
+// `iface` = the incident face.  The caller fills in the other fields of the manifold.
+//
+// Scratch (LDS, all of it owned by the group): `poly0` / `poly1` = the clipper's ping-pong polygons, P rows each
+// (P = polygon capacity = one vertex per lane, at most 16); `ref` = kMaxFaceVerts rows for the reference face.  The
+// polygons may alias anything the caller no longer needs, `ref` may alias world_i: the block is one wave and its LDS
+// accesses execute in program order -- every lane's read of an instruction has been issued before any lane's write of a
+// later one -- so the incident face is copied out before the reference face overwrites the incident body's vertices.
+template <uint32_t L, uint32_t P, class M>
+__device__ __forceinline__ uint32_t face_contact_group(const PolytopeTables &t, const ShapeDesc &dr, const ShapeDesc &di,
+                                                       const Frame &fr, const Frame &fi, uint32_t ref_face,
+                                                       const double (*world_r)[3], const double (*world_i)[3],
+                                                       double (*poly0)[3], double (*poly1)[3], double (*ref)[3], M *m,
+                                                       uint32_t lane, uint32_t &iface)
+{
+    static_assert(P <= L && P <= 16, "one polygon vertex per lane");
+    const double *rp = t.planes + 4 * (size_t)(dr.face0 + ref_face);
+    const Plane ref_plane = fr * Plane{Vec3{rp[0], rp[1], rp[2]}, rp[3]}; // frames.0 * polytopes.0.plane(face), :66
+
+    // incident face: least normal . ref_normal, first minimum (:76-85); faces strided over the group
+    double idot = DBL_MAX;
+    iface = 0xFFFFFFFFu;
+    for (uint32_t f = lane; f < di.n_faces; f += L) {
+        const double *pl = t.planes + 4 * (size_t)(di.face0 + f);
+        const Plane w = fi * Plane{Vec3{pl[0], pl[1], pl[2]}, pl[3]};
+        const double d = dot(w.normal, ref_plane.normal);
+        if (d < idot) { // ascending f on this lane: first minimum
+            idot = d;
+            iface = f;
+        }
+    }
+    reduce_min_first(idot, iface, L);
+    if (iface == 0xFFFFFFFFu)
+        iface = 0;
+
+    // Sutherland-Hodgman with ONE POLYGON VERTEX PER LANE (polygons have <= 16 vertices): every lane
+    // tests its edge (p0 -> p1) against the side plane, a prefix sum of the 0/1/2 points it emits
+    // gives their slots, so the output order is exactly that of the sequential algorithm.
+    const uint32_t *rv = t.face_verts + t.face_start[dr.face0 + ref_face];
+    const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
+    const uint32_t *iv = t.face_verts + t.face_start[di.face0 + iface];
+    uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
+    Vec3 inc_vertex{0.0, 0.0, 0.0}, ref_vertex{0.0, 0.0, 0.0};
+    if (lane < np)
+        inc_vertex = ld3(world_i, iv[lane]);
+    if (lane < nr && lane < kMaxFaceVerts)
+        ref_vertex = ld3(world_r, rv[lane]);
+    __syncthreads();
+    // the reference face's vertices by index once, lane-parallel: the clipping loop below then reads LDS only
+    // (phase timing: the three dependent global index loads per side plane were ~40 % of the loop)
+    if (lane < np)
+        st3(poly0, lane, inc_vertex);
+    if (lane < nr && lane < kMaxFaceVerts)
+        st3(ref, lane, ref_vertex);
+    __syncthreads();
+    double(*cur)[3] = poly0, (*nxt)[3] = poly1;
+    for (uint32_t e = 0; e < nr && np > 0; ++e) {
+        const Vec3 a = ld3(ref, e), bnext = ld3(ref, (e + 1) % nr);
+        const Vec3 c = ld3(ref, (e + 2) % nr);
+        Vec3 side = cross(bnext - a, ref_plane.normal);
+        if (dot(side, c - a) > 0.0)
+            side = -side;
+        Vec3 p0{0.0, 0.0, 0.0}, p1{0.0, 0.0, 0.0};
+        double d0 = 0.0, d1 = 0.0;
+        bool in0 = false, crossing = false;
+        if (lane < np) {
+            p0 = ld3(cur, lane);
+            p1 = ld3(cur, lane + 1 == np ? 0u : lane + 1);
+            d0 = dot(side, p0 - a);
+            d1 = dot(side, p1 - a);
+            in0 = d0 <= 0.0;
+            crossing = in0 != (d1 <= 0.0);
+        }
+        // slots of the 0 / 1 / 2 points a lane emits = points emitted by the lanes below it: two ballots and popcounts
+        // over the group's bits of the wave mask (a shuffle scan would be log2(P) round trips)
+        const uint64_t in_bits = group_bits<L>(__ballot(in0)), cross_bits = group_bits<L>(__ballot(crossing));
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint32_t total = (uint32_t)(__popcll(in_bits) + __popcll(cross_bits));
+        uint32_t slot = (uint32_t)(__popcll(in_bits & below) + __popcll(cross_bits & below));
+        if (in0 && slot < P)
+            st3(nxt, slot++, p0);
+        if (crossing && slot < P)
+            st3(nxt, slot, p0 + (p1 - p0) * (d0 / (d0 - d1)));
+        np = total < P ? total : P;
+        double(*const swap)[3] = cur;
+        cur = nxt;
+        nxt = swap;
+        __syncthreads();
+    }
+    // every clipped point strictly below the reference plane is a contact, in polygon order
+    Vec3 pt{0.0, 0.0, 0.0};
+    double depth = 0.0;
+    bool keep = false;
+    if (lane < np) {
+        pt = ld3(cur, lane);
+        depth = distance(ref_plane, pt);
+        keep = !(depth >= 0.0);
+    }
+    const uint64_t keep_bits = group_bits<L>(__ballot(keep));
+    const uint32_t kept = (uint32_t)__popcll(keep_bits);
+    const uint32_t at = (uint32_t)__popcll(keep_bits & ((1ull << lane) - 1ull));
+    if (keep && at < kMaxManifoldPoints) {
+        const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
+        set_point(*m, at, pt, on_ref);
+    }
+    return kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
+}
+
+} // namespace xpbd

@@ -10,6 +10,7 @@ constexpr uint32_t kMaxEpaIters = 48;
 constexpr uint32_t kMaxEpaVerts = 52;   // 4 + kMaxEpaIters
 constexpr uint32_t kMaxEpaFaces = 128;
 constexpr double kEpaTolerance = 1e-10;
+constexpr double kEpaCoplanar = 1e-12;  // a face this close to the new point's plane counts as seeing it (re-triangulated with it)
 
 // xpbd_gjk_result in include/xpbd.h has this layout (96 bytes).
 struct GjkResult {

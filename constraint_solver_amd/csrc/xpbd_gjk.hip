@@ -22,6 +22,7 @@
 #include <climits>
 #include <type_traits>
 
+#include "xpbd_clip.hpp"
 #include "xpbd_device.hpp"
 #include "xpbd_gjk.h"
 
@@ -70,20 +71,6 @@ struct MVert {
     uint32_t ia, ib;  // a = A's world vertex ia, b = B's world vertex ib
 };
 
-__device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
-__device__ __forceinline__ void st3(double (*a)[3], uint32_t k, Vec3 v)
-{
-    a[k][0] = v.x;
-    a[k][1] = v.y;
-    a[k][2] = v.z;
-}
-
-__device__ __forceinline__ long long total_key(double v)
-{
-    const long long i = __double_as_longlong(v);
-    return i ^ (long long)((unsigned long long)(i >> 63) >> 1);
-}
-
 // support(A, d) - support(B, -d) by a group of L lanes (`lane` = lane inside the group); all lanes of the
 // group return the same value.
 template <uint32_t L, class Verts>
@@ -119,6 +106,19 @@ __device__ __forceinline__ MVert minkowski_support(const Verts &s, uint32_t na, 
 __device__ __forceinline__ Vec3 triple(Vec3 a, Vec3 b, Vec3 c) { return cross(cross(a, b), c); }
 __device__ __forceinline__ bool same_dir(Vec3 a, Vec3 b) { return dot(a, b) > 0.0; }
 
+// Search direction from the segment (direction ab) towards the origin (ao = origin - a).  With the origin ON the segment's
+// line the triple product vanishes -- two boxes stacked exactly on top of each other start like this -- and any
+// perpendicular of ab will do: ab x the coordinate axis ab has the least extent along (first minimum).
+__device__ __forceinline__ Vec3 edge_direction(Vec3 ab, Vec3 ao)
+{
+    const Vec3 d = triple(ab, ao, ab);
+    if (dot(d, d) > 0.0)
+        return d;
+    const double ax = fabs(ab.x), ay = fabs(ab.y), az = fabs(ab.z);
+    const Vec3 e = (ax <= ay && ax <= az) ? Vec3{1.0, 0.0, 0.0} : (ay <= az ? Vec3{0.0, 1.0, 0.0} : Vec3{0.0, 0.0, 1.0});
+    return cross(ab, e);
+}
+
 // Triangle case of the boolean GJK: A newest, then B, C.  Rewrites (s0, s1, s2, n) and the direction.
 __device__ __forceinline__ void simplex3(const MVert &A, const MVert &B, const MVert &C, MVert &s0, MVert &s1, MVert &s2,
                                          uint32_t &n, Vec3 &d)
@@ -127,10 +127,10 @@ __device__ __forceinline__ void simplex3(const MVert &A, const MVert &B, const M
     if (same_dir(cross(abc, ac), ao)) {
         if (same_dir(ac, ao)) {
             s0 = C, s1 = A, n = 2;
-            d = triple(ac, ao, ac);
+            d = edge_direction(ac, ao);
         } else if (same_dir(ab, ao)) {
             s0 = B, s1 = A, n = 2;
-            d = triple(ab, ao, ab);
+            d = edge_direction(ab, ao);
         } else {
             s0 = A, n = 1;
             d = ao;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void simplex3(const MVert &A, const MVert &B, const M
     } else if (same_dir(cross(ab, abc), ao)) {
         if (same_dir(ab, ao)) {
             s0 = B, s1 = A, n = 2;
-            d = triple(ab, ao, ab);
+            d = edge_direction(ab, ao);
         } else {
             s0 = A, n = 1;
             d = ao;
@@ -159,9 +159,12 @@ struct Face {
     bool ok;
 };
 
-// Face (i0, i1, i2) of the polytope with its normal turned away from the origin (which is inside).
+// Face (i0, i1, i2) of the polytope.  `opposite` = a vertex known to lie behind the face (the fourth vertex of the first
+// tetrahedron): the winding is flipped so that the normal points away from it.  kNone = trust the winding: a new face
+// (a, b, p) over a horizon edge a -> b inherits the outward winding of the visible face the edge came from.  (The sign of
+// the origin's distance is rounding noise exactly where it matters: origin ON a face of the first tetrahedron.)
 template <class S>
-__device__ __forceinline__ Face make_face(const S &s, uint32_t i0, uint32_t i1, uint32_t i2)
+__device__ __forceinline__ Face make_face(const S &s, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t opposite)
 {
     Face f;
     const Vec3 p0 = ld3(s.vw, i0);
@@ -169,17 +172,19 @@ __device__ __forceinline__ Face make_face(const S &s, uint32_t i0, uint32_t i1, 
     const double len = length(n);
     f.ok = len > 0.0;
     n = n * (1.0 / len);
-    double dist = dot(n, p0);
-    if (dist < 0.0) {
-        const uint32_t t = i1;
-        i1 = i2;
-        i2 = t;
-        n = -n;
-        dist = -dist;
+    if (opposite != kNone) {
+        const double side = dot(n, ld3(s.vw, opposite) - p0);
+        f.ok = f.ok && side != 0.0; // flat tetrahedron
+        if (side > 0.0) {
+            const uint32_t t = i1;
+            i1 = i2;
+            i2 = t;
+            n = -n;
+        }
     }
     f.i0 = i0, f.i1 = i1, f.i2 = i2;
     f.n = n;
-    f.dist = dist;
+    f.dist = dot(n, p0);
     return f;
 }
 
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
                 n = 2;
                 const Vec3 a = s1.w, ab = s0.w - a, ao = -a;
                 if (same_dir(ab, ao)) {
-                    d = triple(ab, ao, ab);
+                    d = edge_direction(ab, ao);
                 } else {
                     s0 = s1;
                     n = 1;
@@ -422,6 +427,88 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     GJK_TICK(3); // verdicts and hit list
 }
 
+// Result of a finished expansion: the witness points of the closest face `best` (barycentric coordinates of the origin's
+// projection), and the contact manifold of the pair.
+//
+// The manifold (extension decision; checker gjk_manifold of oracle/xpbd_pairs_oracle.c): EPA yields ONE point per pair,
+// which lets a box resting on a face rock about that point from substep to substep.  Where the penetration normal is a
+// face normal of one of the bodies (the face of A most aligned with n, or the face of B most aligned with -n, within
+// kFaceAlign) that face becomes the reference face of a clipped face contact exactly as in the SAT (A on ties); any
+// other normal -- an edge-edge contact -- and a clip that leaves no point below the reference plane keep the one point.
+// The clipper's polygons and reference face reuse the polytope's vertex rows (vw / va / vb): the expansion is over.
+constexpr double kFaceAlign = 0.999; // cosine: 2.6 degrees
+
+template <uint32_t L, class S>
+__device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const ShapeDesc &da, const ShapeDesc &db, const Frame &fa,
+                                         const Frame &fb, uint32_t best, double best_dist, GjkResult *__restrict__ r,
+                                         ContactManifold *__restrict__ mf, uint32_t lane)
+{
+    constexpr uint32_t P = L < 16 ? L : 16;
+    static_assert(sizeof(s.vw) >= P * 3 * sizeof(double) && sizeof(s.vb) >= kMaxFaceVerts * 3 * sizeof(double),
+                  "the clipper reuses the polytope's vertex rows");
+    const Vec3 nrm = ld3(s.fn, best);
+    Vec3 pa{0.0, 0.0, 0.0}, pb{0.0, 0.0, 0.0};
+    if (lane == 0) {
+        const uint32_t i0 = s.fi[best][0], i1 = s.fi[best][1], i2 = s.fi[best][2];
+        const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
+        const Vec3 v0 = ld3(s.vw, i1) - aw, v1 = ld3(s.vw, i2) - aw, v2 = proj - aw;
+        const double d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+        const double denom = d00 * d11 - d01 * d01;
+        const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
+        pa = ld3(s.va, i0) * bu + ld3(s.va, i1) * bv + ld3(s.va, i2) * bw;
+        pb = ld3(s.vb, i0) * bu + ld3(s.vb, i1) * bv + ld3(s.vb, i2) * bw;
+        if (r) {
+            r->depth = best_dist;
+            r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
+            r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
+            r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
+        }
+    }
+    if (!mf) // group-uniform
+        return;
+    // face of A most aligned with n, face of B most aligned with -n (first maximum)
+    double align[2];
+    uint32_t face[2];
+    for (uint32_t side = 0; side < 2; ++side) {
+        const ShapeDesc &d = side ? db : da;
+        const Frame &f = side ? fb : fa;
+        const Vec3 n = side ? -nrm : nrm;
+        double top = -DBL_MAX;
+        uint32_t idx = kNone;
+        for (uint32_t k = lane; k < d.n_faces; k += L) {
+            const double *pl = t.planes + 4 * (size_t)(d.face0 + k);
+            const Plane w = f * Plane{Vec3{pl[0], pl[1], pl[2]}, pl[3]};
+            const double a = dot(w.normal, n);
+            if (a > top) {
+                top = a;
+                idx = k;
+            }
+        }
+        reduce_max_first(top, idx, L);
+        align[side] = top;
+        face[side] = idx;
+    }
+    uint32_t n_out = 0, iface = 0;
+    const uint32_t ref = align[0] >= align[1] ? 0u : 1u; // reference body: 0 = A, 1 = B
+    if ((align[0] > align[1] ? align[0] : align[1]) >= kFaceAlign) // group-uniform
+        n_out = face_contact_group<L, P>(t, ref ? db : da, ref ? da : db, ref ? fb : fa, ref ? fa : fb, face[ref], ref ? s.wb : s.wa,
+                                         ref ? s.wa : s.wb, s.vw, s.va, s.vb, mf, lane, iface);
+    if (lane != 0)
+        return;
+    mf->separation = -best_dist;
+    if (n_out) {
+        mf->n_points = n_out;
+        mf->feature = ref;
+        mf->index_a = ref ? iface : face[0];
+        mf->index_b = ref ? face[1] : iface;
+    } else {
+        mf->n_points = 1;
+        mf->feature = 2; // reference body A, incident body B
+        mf->index_a = mf->index_b = 0;
+        set_point(*mf, 0, pb, pa); // pb on the incident body B, pa on the reference body A
+    }
+}
+
 // EPA of one penetrating pair by one wave; the polytope starts from the simplex k_gjk_pairs left.
 __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
@@ -462,7 +549,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
             const uint32_t t0 = lane == 3 ? 1u : 0u;
             const uint32_t t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
             const uint32_t t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
-            const Face f = make_face(s, t0, t1, t2); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}
+            const Face f = make_face(s, t0, t1, t2, 3u - lane); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}: face k lacks vertex 3 - k
             store_face(s, lane, f);
             bad = !f.ok;
         }
@@ -484,8 +571,8 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 
         // visibility of "my" two faces (lane, lane + 64); the masks are wave-uniform
         const uint32_t f0 = lane, f1 = lane + 64;
-        const bool vis0 = f0 < nf && dot(ld3(s.fn, f0), pnt.w - ld3(s.vw, s.fi[f0][0])) > 0.0;
-        const bool vis1 = f1 < nf && dot(ld3(s.fn, f1), pnt.w - ld3(s.vw, s.fi[f1][0])) > 0.0;
+        const bool vis0 = f0 < nf && dot(ld3(s.fn, f0), pnt.w - ld3(s.vw, s.fi[f0][0])) > -kEpaCoplanar;
+        const bool vis1 = f1 < nf && dot(ld3(s.fn, f1), pnt.w - ld3(s.vw, s.fi[f1][0])) > -kEpaCoplanar;
         const unsigned long long mask0 = __ballot(vis0), mask1 = __ballot(vis1);
 
         // horizon test of my faces' edges: a->b is on the horizon iff no other VISIBLE face holds b->a (a face never holds
@@ -574,7 +661,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
             uint32_t slot = keep + (w ? epos1 : epos0);
             for (uint32_t e = 0; e < 3; ++e)
                 if (hz[w] & (1u << e)) {
-                    const Face f = make_face(s, edge_a[w][e], edge_b[w][e], nv);
+                    const Face f = make_face(s, edge_a[w][e], edge_b[w][e], nv, kNone);
                     store_face(s, slot++, f);
                     bad |= !f.ok;
                 }
@@ -590,31 +677,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 
     double best_dist;
     const uint32_t best = closest_face(s, nf, lane, &best_dist);
-    if (lane == 0) {
-        const uint32_t i0 = s.fi[best][0], i1 = s.fi[best][1], i2 = s.fi[best][2];
-        const Vec3 nrm = ld3(s.fn, best);
-        const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
-        const Vec3 v0 = ld3(s.vw, i1) - aw, v1 = ld3(s.vw, i2) - aw, v2 = proj - aw;
-        const double d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
-        const double denom = d00 * d11 - d01 * d01;
-        const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
-        const Vec3 pa = ld3(s.va, i0) * bu + ld3(s.va, i1) * bv + ld3(s.va, i2) * bw;
-        const Vec3 pb = ld3(s.vb, i0) * bu + ld3(s.vb, i1) * bv + ld3(s.vb, i2) * bw;
-        if (r) {
-            r->depth = best_dist;
-            r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
-            r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
-            r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
-        }
-        if (mf) {
-            mf->n_points = 1;
-            mf->feature = 2; // reference body A, incident body B
-            mf->index_a = mf->index_b = 0;
-            mf->separation = -best_dist;
-            mf->point[0][1][0] = pa.x, mf->point[0][1][1] = pa.y, mf->point[0][1][2] = pa.z; // on the reference body A
-            mf->point[0][0][0] = pb.x, mf->point[0][0][1] = pb.y, mf->point[0][0][2] = pb.z; // on the incident body B
-        }
-    }
+    epa_emit<64>(s, t, da, db, fa, fb, best, best_dist, r, mf, lane);
     finish(1);
 }
 
@@ -667,10 +730,11 @@ constexpr uint32_t kSubVerts = 16;      // shape vertices per body
 #define XPBD_EPA_SUB_POLY_VERTS 20      // 4 + 16 expansions (a build with 6 sends most hits through the overflow path: used to test it)
 #endif
 constexpr uint32_t kSubPolyVerts = XPBD_EPA_SUB_POLY_VERTS;
+constexpr uint32_t kSubRows = kSubPolyVerts < 16 ? 16 : kSubPolyVerts; // the clipper needs 16 rows
 constexpr uint32_t kSubPolyFaces = 2 * kSubPolyVerts - 4; // Euler: a closed triangulated polytope with V vertices has 2 V - 4 faces
 
 struct EpaSubLds : GjkVertsT<kSubVerts> {
-    double vw[kSubPolyVerts][3], va[kSubPolyVerts][3], vb[kSubPolyVerts][3];
+    double vw[kSubRows][3], va[kSubRows][3], vb[kSubRows][3]; // (then the clipper's polygons and reference face)
     uint32_t fi[kSubPolyFaces][3];
     double fn[kSubPolyFaces][3];
     double fd[kSubPolyFaces];
@@ -748,7 +812,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
             const uint32_t t0 = lane == 3 ? 1u : 0u;
             const uint32_t t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
             const uint32_t t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
-            const Face f = make_face(s, t0, t1, t2); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}
+            const Face f = make_face(s, t0, t1, t2, 3u - lane); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}: face k lacks vertex 3 - k
             store_face(s, lane, f);
             bad = !f.ok;
         }
@@ -776,7 +840,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const uint32_t f = lane + L * j;
-            my_vis[j] = f < nf && dot(ld3(s.fn, f), pnt.w - ld3(s.vw, s.fi[f][0])) > 0.0;
+            my_vis[j] = f < nf && dot(ld3(s.fn, f), pnt.w - ld3(s.vw, s.fi[f][0])) > -kEpaCoplanar;
             vis |= group_ballot<L>(my_vis[j]) << (L * j);
             valid |= group_ballot<L>(f < nf) << (L * j);
         }
@@ -855,7 +919,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
             const uint32_t ea[3] = {mine[j].i0, mine[j].i1, mine[j].i2}, eb[3] = {mine[j].i1, mine[j].i2, mine[j].i0};
             for (uint32_t e = 0; e < 3; ++e)
                 if (hz[j] & (1u << e)) {
-                    const Face nfce = make_face(s, ea[e], eb[e], nv);
+                    const Face nfce = make_face(s, ea[e], eb[e], nv, kNone);
                     store_face(s, slot++, nfce);
                     bad |= !nfce.ok;
                 }
@@ -871,31 +935,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 
     double best_dist;
     const uint32_t best = closest(nf, &best_dist);
-    if (lane == 0) {
-        const uint32_t i0 = s.fi[best][0], i1 = s.fi[best][1], i2 = s.fi[best][2];
-        const Vec3 nrm = ld3(s.fn, best);
-        const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
-        const Vec3 v0 = ld3(s.vw, i1) - aw, v1 = ld3(s.vw, i2) - aw, v2 = proj - aw;
-        const double d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
-        const double denom = d00 * d11 - d01 * d01;
-        const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
-        const Vec3 pa = ld3(s.va, i0) * bu + ld3(s.va, i1) * bv + ld3(s.va, i2) * bw;
-        const Vec3 pb = ld3(s.vb, i0) * bu + ld3(s.vb, i1) * bv + ld3(s.vb, i2) * bw;
-        if (r) {
-            r->depth = best_dist;
-            r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
-            r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
-            r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
-        }
-        if (mf) {
-            mf->n_points = 1;
-            mf->feature = 2; // reference body A, incident body B
-            mf->index_a = mf->index_b = 0;
-            mf->separation = -best_dist;
-            mf->point[0][1][0] = pa.x, mf->point[0][1][1] = pa.y, mf->point[0][1][2] = pa.z; // on the reference body A
-            mf->point[0][0][0] = pb.x, mf->point[0][0][1] = pb.y, mf->point[0][0][2] = pb.z; // on the incident body B
-        }
-    }
+    epa_emit<L>(s, t, da, db, fa, fb, best, best_dist, r, mf, lane);
     finish(1);
     return true;
 }

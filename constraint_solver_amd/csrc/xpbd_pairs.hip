@@ -22,6 +22,7 @@
 
 #include <type_traits>
 
+#include "xpbd_clip.hpp"
 #include "xpbd_device.hpp"
 #include "xpbd_pairs.h"
 
@@ -82,21 +83,6 @@ struct PairLds {
     uint32_t pad[kPadDwords ? kPadDwords : 2];
 };
 
-__device__ __forceinline__ Vec3 ld3(const double (*a)[3], uint32_t k) { return Vec3{a[k][0], a[k][1], a[k][2]}; }
-__device__ __forceinline__ void st3(double (*a)[3], uint32_t k, Vec3 v)
-{
-    a[k][0] = v.x;
-    a[k][1] = v.y;
-    a[k][2] = v.z;
-}
-
-// Key whose signed-integer order is IEEE totalOrder (Rust f64::total_cmp).
-__device__ __forceinline__ long long total_key(double v)
-{
-    const long long i = __double_as_longlong(v);
-    return i ^ (long long)((unsigned long long)(i >> 63) >> 1);
-}
-
 __device__ __forceinline__ bool finite3(Vec3 v)
 {
     return fabs(v.x) <= DBL_MAX && fabs(v.y) <= DBL_MAX && fabs(v.z) <= DBL_MAX;
@@ -118,40 +104,6 @@ __device__ __forceinline__ Vec3 support_last_max(const double (*verts)[3], uint3
     return best;
 }
 
-// (value, index) reductions over `width` consecutive lanes (a power of two; xor offsets < width stay inside
-// the aligned group).
-__device__ __forceinline__ void reduce_max_first(double &v, uint32_t &idx, uint32_t width)
-{
-    for (uint32_t off = width >> 1; off; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(idx, off, 64);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
-    }
-}
-
-__device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint32_t width)
-{
-    for (uint32_t off = width >> 1; off; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(idx, off, 64);
-        if (ov < v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
-    }
-}
-
-// The bits of a wave-wide ballot that belong to the calling lane's group of L lanes, moved down to bit 0.
-template <uint32_t L>
-__device__ __forceinline__ uint64_t group_bits(unsigned long long wave_mask)
-{
-    const uint32_t first = (threadIdx.x & 63u) / L * L; // the block is one wave
-    return L == 64 ? wave_mask : (wave_mask >> first) & ((1ull << (L & 63u)) - 1ull);
-}
-
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
 // The SAT of ONE pair by a group of L lanes (`lane` = lane inside the group, `s` = the group's LDS record).
@@ -160,18 +112,6 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 // width and all shuffles stay inside the group, so every instantiation produces the same bits.  The block is ONE
 // wave, hence __syncthreads() is a wave-local fence and the groups of a wave may diverge freely (one pair separated,
 // the next one clipping).
-// One contact point into either result layout.
-__device__ __forceinline__ void set_point(Manifold &m, uint32_t k, Vec3 inc, Vec3 ref)
-{
-    m.p_inc[k][0] = inc.x, m.p_inc[k][1] = inc.y, m.p_inc[k][2] = inc.z;
-    m.p_ref[k][0] = ref.x, m.p_ref[k][1] = ref.y, m.p_ref[k][2] = ref.z;
-}
-__device__ __forceinline__ void set_point(ContactManifold &m, uint32_t k, Vec3 inc, Vec3 ref)
-{
-    m.point[k][0][0] = inc.x, m.point[k][0][1] = inc.y, m.point[k][0][2] = inc.z;
-    m.point[k][1][0] = ref.x, m.point[k][1][1] = ref.y, m.point[k][1][2] = ref.z;
-}
-
 template <uint32_t L, class Lds, class M>
 __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane)
@@ -371,98 +311,11 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     const uint32_t ref_face = r ? face_b : face_a;
     const Frame fr = r ? fb : fa, fi = r ? fa : fb;
     const ShapeDesc dr = r ? db : da, di = r ? da : db;
-    const double *rp = t.planes + 4 * (size_t)(dr.face0 + ref_face);
-    const Plane ref_plane = fr * Plane{Vec3{rp[0], rp[1], rp[2]}, rp[3]}; // frames.0 * polytopes.0.plane(face), :66
-
-    // incident face: least normal . ref_normal, first minimum (:76-85); faces strided over the group
-    double idot = DBL_MAX;
-    uint32_t iface = kNone;
-    for (uint32_t f = lane; f < di.n_faces; f += L) {
-        const double *pl = t.planes + 4 * (size_t)(di.face0 + f);
-        const Plane w = fi * Plane{Vec3{pl[0], pl[1], pl[2]}, pl[3]};
-        const double d = dot(w.normal, ref_plane.normal);
-        if (d < idot) { // ascending f on this lane: first minimum
-            idot = d;
-            iface = f;
-        }
-    }
-    reduce_min_first(idot, iface, L);
-    if (iface == kNone)
-        iface = 0;
-
-    // Sutherland-Hodgman with ONE POLYGON VERTEX PER LANE (polygons have <= 16 vertices): every lane
-    // tests its edge (p0 -> p1) against the side plane, a prefix sum of the 0/1/2 points it emits
-    // gives their slots, so the output order is exactly that of the sequential algorithm.
-    const uint32_t *rv = t.face_verts + t.face_start[dr.face0 + ref_face];
-    const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
-    const uint32_t *iv = t.face_verts + t.face_start[di.face0 + iface];
-    uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
-    // (the block is one wave and its LDS accesses execute in program order: every lane's read of an instruction has been
-    // issued before any lane's write of a later one, so the polygons may overwrite the edge directions they alias and the
-    // reference face the incident body's vertices)
-    Vec3 inc_vertex{0.0, 0.0, 0.0}, ref_vertex{0.0, 0.0, 0.0};
-    if (lane < np)
-        inc_vertex = ld3(s.world[r ^ 1u], iv[lane]);
-    if (lane < nr && lane < kMaxFaceVerts)
-        ref_vertex = ld3(s.world[r], rv[lane]);
-    __syncthreads();
-    // the reference face's vertices by index once, lane-parallel: the clipping loop below then reads LDS only
-    // (phase timing: the three dependent global index loads per side plane were ~40 % of the loop)
-    double(*const ref)[3] = s.world[r ^ 1u];
-    if (lane < np)
-        st3(s.poly[0], lane, inc_vertex);
-    if (lane < nr && lane < kMaxFaceVerts)
-        st3(ref, lane, ref_vertex);
-    __syncthreads();
-    uint32_t cur = 0;
-    for (uint32_t e = 0; e < nr && np > 0; ++e) {
-        const Vec3 a = ld3(ref, e), bnext = ld3(ref, (e + 1) % nr);
-        const Vec3 c = ld3(ref, (e + 2) % nr);
-        Vec3 side = cross(bnext - a, ref_plane.normal);
-        if (dot(side, c - a) > 0.0)
-            side = -side;
-        Vec3 p0{0.0, 0.0, 0.0}, p1{0.0, 0.0, 0.0};
-        double d0 = 0.0, d1 = 0.0;
-        bool in0 = false, crossing = false;
-        if (lane < np) {
-            p0 = ld3(s.poly[cur], lane);
-            p1 = ld3(s.poly[cur], lane + 1 == np ? 0u : lane + 1);
-            d0 = dot(side, p0 - a);
-            d1 = dot(side, p1 - a);
-            in0 = d0 <= 0.0;
-            crossing = in0 != (d1 <= 0.0);
-        }
-        // slots of the 0 / 1 / 2 points a lane emits = points emitted by the lanes below it: two ballots and popcounts
-        // over the group's bits of the wave mask (a shuffle scan would be log2(P) round trips)
-        const uint64_t in_bits = group_bits<L>(__ballot(in0)), cross_bits = group_bits<L>(__ballot(crossing));
-        const uint64_t below = (1ull << lane) - 1ull;
-        const uint32_t total = (uint32_t)(__popcll(in_bits) + __popcll(cross_bits));
-        uint32_t slot = (uint32_t)(__popcll(in_bits & below) + __popcll(cross_bits & below));
-        if (in0 && slot < P)
-            st3(s.poly[cur ^ 1u], slot++, p0);
-        if (crossing && slot < P)
-            st3(s.poly[cur ^ 1u], slot, p0 + (p1 - p0) * (d0 / (d0 - d1)));
-        np = total < P ? total : P;
-        cur ^= 1u;
-        __syncthreads();
-    }
-    // every clipped point strictly below the reference plane is a contact, in polygon order
-    Vec3 pt{0.0, 0.0, 0.0};
-    double depth = 0.0;
-    bool keep = false;
-    if (lane < np) {
-        pt = ld3(s.poly[cur], lane);
-        depth = distance(ref_plane, pt);
-        keep = !(depth >= 0.0);
-    }
-    const uint64_t keep_bits = group_bits<L>(__ballot(keep));
-    const uint32_t kept = (uint32_t)__popcll(keep_bits);
-    const uint32_t n_out = kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
-    const uint32_t at = (uint32_t)__popcll(keep_bits & ((1ull << lane) - 1ull));
-    if (keep && at < kMaxManifoldPoints) {
-        const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
-        set_point(*m, at, pt, on_ref);
-    }
+    // clipping scratch: the polygons take the place of the edge directions, the reference face that of the INCIDENT
+    // body's world-space vertices (see face_contact_group)
+    uint32_t iface;
+    const uint32_t n_out = face_contact_group<L, P>(t, dr, di, fr, fi, ref_face, s.world[r], s.world[r ^ 1u], s.poly[0], s.poly[1],
+                                                    s.world[r ^ 1u], m, lane, iface);
     if (lane != 0)
         return;
     m->n_points = n_out;

@@ -58,13 +58,27 @@ static mvert minkowski_support(const shapes_t *s, o_vec3 d)
 static o_vec3 triple(o_vec3 a, o_vec3 b, o_vec3 c) { return o_cross(o_cross(a, b), c); } /* (a x b) x c */
 static int same_dir(o_vec3 a, o_vec3 b) { return o_dot(a, b) > 0.0; }
 
+/* Search direction from the segment (direction ab) towards the origin (ao = origin - a).  If the origin lies on the
+ * segment's line the triple product vanishes -- two boxes stacked exactly on top of each other start like this, the
+ * first two support points being (0, 0, depth) and (0, 0, depth - 2) -- and any perpendicular of ab will do: ab x the
+ * coordinate axis ab has the least extent along (first minimum). */
+static o_vec3 edge_direction(o_vec3 ab, o_vec3 ao)
+{
+    o_vec3 d = triple(ab, ao, ab);
+    if (o_dot(d, d) > 0.0)
+        return d;
+    double ax = fabs(ab.x), ay = fabs(ab.y), az = fabs(ab.z);
+    o_vec3 e = (ax <= ay && ax <= az) ? (o_vec3){ 1.0, 0.0, 0.0 } : (ay <= az ? (o_vec3){ 0.0, 1.0, 0.0 } : (o_vec3){ 0.0, 0.0, 1.0 });
+    return o_cross(ab, e);
+}
+
 /* Simplex update of the boolean GJK: s[n-1] is the newest point.  Returns 1 when the origin is enclosed. */
 static int do_simplex(mvert *s, uint32_t *n, o_vec3 *d)
 {
     if (*n == 2) {
         o_vec3 a = s[1].w, b = s[0].w, ab = o_sub(b, a), ao = o_neg(a);
         if (same_dir(ab, ao)) {
-            *d = triple(ab, ao, ab);
+            *d = edge_direction(ab, ao);
         } else {
             s[0] = s[1];
             *n = 1;
@@ -78,10 +92,10 @@ static int do_simplex(mvert *s, uint32_t *n, o_vec3 *d)
         if (same_dir(o_cross(abc, ac), ao)) {
             if (same_dir(ac, ao)) {
                 s[0] = Cc, s[1] = A, *n = 2;
-                *d = triple(ac, ao, ac);
+                *d = edge_direction(ac, ao);
             } else if (same_dir(ab, ao)) {
                 s[0] = B, s[1] = A, *n = 2;
-                *d = triple(ab, ao, ab);
+                *d = edge_direction(ab, ao);
             } else {
                 s[0] = A, *n = 1;
                 *d = ao;
@@ -89,7 +103,7 @@ static int do_simplex(mvert *s, uint32_t *n, o_vec3 *d)
         } else if (same_dir(o_cross(ab, abc), ao)) {
             if (same_dir(ab, ao)) {
                 s[0] = B, s[1] = A, *n = 2;
-                *d = triple(ab, ao, ab);
+                *d = edge_direction(ab, ao);
             } else {
                 s[0] = A, *n = 1;
                 *d = ao;
@@ -127,24 +141,33 @@ static int do_simplex(mvert *s, uint32_t *n, o_vec3 *d)
 /* ---- EPA ------------------------------------------------------------------------------------ */
 typedef struct { uint32_t i[3]; o_vec3 n; double dist; } eface;
 
-static int make_face(const mvert *v, uint32_t i0, uint32_t i1, uint32_t i2, eface *f)
+/* Face (i0, i1, i2) of the polytope.  `opposite` = a vertex known to lie behind the face (the fourth vertex of the
+ * initial tetrahedron): the winding is flipped so that the normal points away from it.  OG_NO_VERTEX = trust the
+ * winding: a new face (a, b, p) over a horizon edge a -> b inherits the outward winding of the visible face the
+ * edge came from.  (Orienting by the sign of the origin's distance instead breaks down exactly where it matters:
+ * with the origin ON a face of the first tetrahedron -- exactly aligned boxes -- that sign is rounding noise.) */
+#define OG_NO_VERTEX 0xFFFFFFFFu
+static int make_face(const mvert *v, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t opposite, eface *f)
 {
     o_vec3 n = o_cross(o_sub(v[i1].w, v[i0].w), o_sub(v[i2].w, v[i0].w));
     double len = o_magnitude(n);
     if (!(len > 0.0))
         return 0; /* degenerate (collinear) face */
     n = o_scale(n, 1.0 / len);
-    double dist = o_dot(n, v[i0].w);
-    if (dist < 0.0) { /* orient outward: the origin is inside the polytope */
-        uint32_t t = i1;
-        i1 = i2;
-        i2 = t;
-        n = o_neg(n);
-        dist = -dist;
+    if (opposite != OG_NO_VERTEX) {
+        double side = o_dot(n, o_sub(v[opposite].w, v[i0].w));
+        if (!(side != 0.0))
+            return 0; /* flat tetrahedron */
+        if (side > 0.0) {
+            uint32_t t = i1;
+            i1 = i2;
+            i2 = t;
+            n = o_neg(n);
+        }
     }
     f->i[0] = i0, f->i[1] = i1, f->i[2] = i2;
     f->n = n;
-    f->dist = dist;
+    f->dist = o_dot(n, v[i0].w);
     return 1;
 }
 
@@ -196,9 +219,9 @@ void og_gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *
     eface f[OG_MAX_EPA_FACES];
     uint32_t nv = 4, nf = 0;
     memcpy(v, sx, sizeof(mvert) * 4);
-    static const uint32_t tet[4][3] = { {0, 1, 2}, {0, 3, 1}, {0, 2, 3}, {1, 3, 2} };
-    for (int k = 0; k < 4; k++)
-        if (!make_face(v, tet[k][0], tet[k][1], tet[k][2], &f[nf++])) {
+    static const uint32_t tet[4][3] = { {0, 1, 2}, {0, 3, 1}, {0, 2, 3}, {1, 3, 2} }; /* face k lacks vertex 3 - k */
+    for (int k = 0; k < 4; k++) /* the vertex opposite face k is 3 - k */
+        if (!make_face(v, tet[k][0], tet[k][1], tet[k][2], 3u - (uint32_t)k, &f[nf++])) {
             out->status = OG_DEGENERATE; /* flat tetrahedron */
             return;
         }
@@ -213,14 +236,17 @@ void og_gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *
         double reach = o_dot(p.w, f[best].n);
         if (reach - f[best].dist < OG_EPA_TOLERANCE || nv == OG_MAX_EPA_VERTS)
             break;
-        /* Faces that see the new point are removed and their boundary (the horizon) is re-triangulated.
+        /* Faces that see the new point are removed and their boundary (the horizon) is re-triangulated.  A face the
+         * point is coplanar with (within OG_EPA_COPLANAR) counts as seeing it: were it kept, a new point on the line
+         * of one of its edges -- the Minkowski difference of two aligned boxes is a 3 x 3 x 3 grid of points -- would
+         * close the horizon with a face of no area.
          * Canonical order, so that a parallel implementation reproduces it exactly: surviving faces keep
          * their relative order; horizon edges are listed by (visible face, edge) ascending, an edge a->b
          * of a visible face being on the horizon iff no other VISIBLE face holds b->a. */
         uint32_t edges[OG_MAX_EPA_FACES * 3][2], ne = 0;
         uint8_t visible[OG_MAX_EPA_FACES];
         for (uint32_t k = 0; k < nf; k++)
-            visible[k] = o_dot(f[k].n, o_sub(p.w, v[f[k].i[0]].w)) > 0.0;
+            visible[k] = o_dot(f[k].n, o_sub(p.w, v[f[k].i[0]].w)) > -OG_EPA_COPLANAR;
         for (uint32_t k = 0; k < nf; k++) {
             if (!visible[k])
                 continue;
@@ -254,7 +280,7 @@ void og_gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *
         v[nv] = p;
         int ok = 1;
         for (uint32_t q = 0; q < ne; q++)
-            if (!make_face(v, edges[q][0], edges[q][1], nv, &f[nf++])) {
+            if (!make_face(v, edges[q][0], edges[q][1], nv, OG_NO_VERTEX, &f[nf++])) {
                 ok = 0;
                 break;
             }

@@ -20,6 +20,7 @@ extern "C" {
 #define OG_MAX_EPA_VERTS 52   /* 4 + OG_MAX_EPA_ITERS */
 #define OG_MAX_EPA_FACES 128
 #define OG_EPA_TOLERANCE 1e-10
+#define OG_EPA_COPLANAR  1e-12 /* a face this close to the new point's plane is re-triangulated with it */
 
 typedef struct {
     int32_t  status;

@@ -399,7 +399,15 @@ struct op_frame {
 
 void op_contacts_set_narrowphase(op_frame *f, int narrowphase) { f->narrowphase = narrowphase; }
 
-/* GJK + EPA result as a one-point manifold: A is the reference body, B the incident one. */
+/*
+ * GJK + EPA result as a contact manifold (extension decision; nothing of this exists in the reference).
+ * EPA yields one point per pair; a box resting on a face would rock about it.  Where the penetration normal n (from A
+ * towards B) is a face normal of one of the bodies -- the face of A most aligned with n, or the face of B most aligned
+ * with -n, cosine >= OP_FACE_ALIGN, first maximum, A on ties -- that face is the reference face of a clipped face contact
+ * exactly as in the SAT.  Any other normal (an edge-edge contact), and a clip that leaves no point below the reference
+ * plane, keep the one EPA point with A as the reference body.  The separation is -depth either way.
+ */
+#define OP_FACE_ALIGN 0.999
 static void gjk_manifold(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, op_manifold *m)
 {
     og_result r;
@@ -408,11 +416,39 @@ static void gjk_manifold(o_frame fa, o_frame fb, const o_polytope *pa, const o_p
     m->separated = r.status != OG_PENETRATING; /* a degenerate query yields no contact in this substep */
     if (m->separated)
         return;
-    m->feature = OP_FEATURE_EDGES;
+    double align[2] = { -DBL_MAX, -DBL_MAX };
+    uint32_t face[2] = { UINT32_MAX, UINT32_MAX };
+    for (int side = 0; side < 2; side++) {
+        const o_polytope *p = side ? pb : pa;
+        o_frame f = side ? fb : fa;
+        o_vec3 n = side ? o_neg(r.normal) : r.normal;
+        for (uint32_t k = 0; k < p->n_faces; k++) {
+            double a = o_dot(o_frame_mulplane(f, o_polytope_plane(p, k)).normal, n);
+            if (a > align[side]) {
+                align[side] = a;
+                face[side] = k;
+            }
+        }
+    }
+    if ((align[0] > align[1] ? align[0] : align[1]) >= OP_FACE_ALIGN) {
+        if (align[0] >= align[1]) {
+            m->feature = OP_FEATURE_FACE_A;
+            m->index_a = face[0];
+            face_contact(fa, pa, face[0], fb, pb, &m->index_b, m);
+        } else {
+            m->feature = OP_FEATURE_FACE_B;
+            m->index_b = face[1];
+            face_contact(fb, pb, face[1], fa, pa, &m->index_a, m);
+        }
+    }
     m->separation = -r.depth;
-    m->n_points = 1;
-    m->p_ref[0] = r.point_a;
-    m->p_inc[0] = r.point_b;
+    if (m->n_points == 0) {
+        m->feature = OP_FEATURE_EDGES;
+        m->index_a = m->index_b = 0;
+        m->n_points = 1;
+        m->p_ref[0] = r.point_a;
+        m->p_inc[0] = r.point_b;
+    }
 }
 
 void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_joints)

@@ -26,6 +26,34 @@ def test_axis_aligned_overlap():
     assert ob.gjk_epa(([0, 0, 0], I4), ([0.5, 0, 0], I4), CUBE, empty).status == ob.GJK_SEPARATED
 
 
+def test_exactly_aligned_boxes_are_not_degenerate():
+    """Boxes stacked exactly on top of each other: the first two support points and the origin are collinear, the origin lies
+    on a face of the first tetrahedron and the Minkowski difference is a 3 x 3 x 3 grid of points (collinear triples,
+    coplanar quadruples).  Every such query must still answer; a dropped contact lets a stack sink into itself."""
+    rng = np.random.default_rng(11)
+    for depth in (0.3, 1e-2, 1e-4, 1e-6):
+        for axis in range(3):
+            for shift in ([0.0, 0.0, 0.0], [0.3, -0.2, 0.1], [0.5, 0.5, 0.5]):     # the last: corner over centre
+                at = np.array([0.25, -1.5, 3.0])
+                offset = np.zeros(3)
+                offset[axis] = 1.0 - depth
+                lateral = np.array(shift) * (np.arange(3) != axis)
+                for sign in (1.0, -1.0):
+                    r = ob.gjk_epa((at, I4), (at + sign * offset + lateral, I4), CUBE, CUBE)
+                    assert r.status == ob.GJK_PENETRATING
+                    assert abs(r.depth - depth) < 1e-12
+                    want = np.zeros(3)
+                    want[axis] = sign
+                    np.testing.assert_allclose(r.normal.np(), want, atol=1e-12)
+    # and with rounding-sized perturbations of the pose
+    for noise in (1e-16, 1e-14, 1e-12):
+        for _ in range(300):
+            q = np.array(I4) + rng.normal(size=4) * noise
+            fb = (np.array([rng.normal() * noise, rng.normal() * noise, 1.0 - 1e-4]), q / np.linalg.norm(q))
+            r = ob.gjk_epa(([0.0, 0.0, 0.0], I4), fb, CUBE, CUBE)
+            assert r.status == ob.GJK_PENETRATING and abs(r.depth - 1e-4) < 1e-9 and r.normal.z > 1.0 - 1e-9
+
+
 def test_agrees_with_exact_sat_on_random_pairs():
     rng = np.random.default_rng(5)
     penetrating = separated = 0

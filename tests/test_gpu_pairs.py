@@ -500,14 +500,15 @@ def test_gjk_epa_kernel_matches_oracle(kind, n, spread):
 
 
 def test_contact_pipeline_with_gjk_epa_narrowphase_matches_oracle():
-    """BASELINE configs[2] path in miniature: mixed polyhedra colliding, narrowphase = GJK + EPA (one contact per pair)."""
+    """BASELINE configs[2] path in miniature: mixed polyhedra colliding, narrowphase = GJK + EPA (face manifolds where the
+    penetration normal is a face normal, one point per pair otherwise)."""
     kind, n = capi.SCENE_MIXED_DROP, 180
     bodies, sid = pile(kind, n, 12, 2.5, 6.0)
     polys = ob.polytopes_array(POLY_NAMES[kind])
     none = np.zeros(0, dtype=capi.JOINT_DTYPE)
-    want = bodies
+    want, want_stats = bodies, ob.ContactStats()
     for _ in range(30):
-        want = ob.contacts_step_joints(want, sid, polys, none, DT, 10, 0.02, narrowphase=1)
+        want = ob.contacts_step_joints(want, sid, polys, none, DT, 10, 0.02, narrowphase=1, stats=want_stats)
     with capi.World(mode=capi.MODE_CONTACTS) as w:
         w.set_polytopes(capi.scene_polytopes(kind))
         w.set_narrowphase(capi.NARROWPHASE_GJK_EPA)
@@ -517,7 +518,8 @@ def test_contact_pipeline_with_gjk_epa_narrowphase_matches_oracle():
         stats = w.contact_stats()
         got = w.download()
         assert bits_equal(got, want)
-        assert stats[1] > 50 and stats[2] == stats[1]                 # touching pairs, exactly one point each
+        assert (stats[1], stats[2]) == (want_stats.n_touching, want_stats.n_points)
+        assert stats[1] > 50 and stats[1] < stats[2] < 8 * stats[1]   # touching pairs; face manifolds and single points
         with pytest.raises(capi.XpbdError):
             w.set_narrowphase(7)
     # the SAT path gives a different (multi-point) answer on the same scene
@@ -525,6 +527,55 @@ def test_contact_pipeline_with_gjk_epa_narrowphase_matches_oracle():
     for _ in range(30):
         sat_want, _, _ = ob.contacts_step(sat_want, sid, polys, DT, 10, 0.02)
     assert not bits_equal(sat_want, want)
+
+
+def test_gjk_epa_holds_exactly_aligned_stacks_like_the_oracle():
+    """Boxes stacked exactly on top of each other are the degenerate extreme of GJK + EPA (collinear support points, the
+    origin on a face of the first tetrahedron, a 3 x 3 x 3 grid as Minkowski difference).  No query may be dropped, the
+    manifolds are the SAT's four-point face contacts, and the columns stand -- bit for bit as in the oracle."""
+    n = 64
+    bodies, sid = capi.scene_generate(capi.SCENE_BOXES, 1, n)
+    bodies[:, 34:38] = [1.0, 0.0, 0.0, 0.0]
+    bodies[:, 31:33] = 0.0
+    bodies[:, 33] = np.arange(n) * 0.999                            # a column, 1 mm interpenetration per level
+    pairs = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1).astype(np.uint32)
+    with capi.World() as w:
+        w.set_polytopes(capi.scene_polytopes(capi.SCENE_BOXES))
+        w.upload(bodies, sid)
+        got = w.narrowphase_gjk(pairs)
+    assert (got["status"] == ob.GJK_PENETRATING).all()
+    np.testing.assert_allclose(got["depth"], 0.001, rtol=1e-9)
+    np.testing.assert_allclose(got["normal"], np.tile([0.0, 0.0, 1.0], (n - 1, 1)), atol=1e-12)
+    L, cube = ob.load(), ob.polytope("cube", 1.0)
+    frames = []
+    for b in bodies:
+        f = L.o_rigid_frame(C.byref(ob.Rigid.from_np(b)))
+        frames.append((f.position.np(), f.rotation.np()))
+    for g, (i, j) in zip(got, pairs):
+        r = ob.gjk_epa(frames[i], frames[j], cube, cube)
+        assert (g["status"], g["gjk_iterations"], g["epa_iterations"]) == (r.status, r.gjk_iterations, r.epa_iterations)
+        assert bits_equal(g["normal"], r.normal.np()) and bits_equal(np.array([g["depth"]]), np.array([r.depth]))
+        assert bits_equal(g["point_a"], r.point_a.np()) and bits_equal(g["point_b"], r.point_b.np())
+
+    n, frames = 16 * 16, 12
+    bodies, sid = capi.scene_generate(capi.SCENE_BOX_STACKS, 1, n)
+    polys = ob.polytopes_array([("cube", 1.0)])
+    none = np.zeros(0, dtype=capi.JOINT_DTYPE)
+    want, want_stats = bodies, ob.ContactStats()
+    for _ in range(frames):
+        want = ob.contacts_step_joints(want, sid, polys, none, DT, 20, 0.02, narrowphase=1, stats=want_stats)
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(capi.SCENE_BOX_STACKS))
+        w.set_narrowphase(capi.NARROWPHASE_GJK_EPA)
+        w.upload(bodies, sid)
+        for _ in range(frames):
+            w.step(DT, 20)
+        stats = w.contact_stats()
+        got = w.download()
+    assert bits_equal(got, want)
+    assert (stats[1], stats[2]) == (want_stats.n_touching, want_stats.n_points)
+    assert stats[1] > 0.5 * (n // 16 * 15) * 20 * frames and stats[2] > 3.5 * stats[1]   # the columns touch, four points a pair
+    np.testing.assert_allclose(got[:, 33], np.arange(n) % 16, atol=0.02)                 # and stand
 
 
 def test_narrowphases_on_random_convex_hulls():
