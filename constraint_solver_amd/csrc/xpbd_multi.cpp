@@ -99,6 +99,8 @@ struct DevBuf {
     {
         if (want <= bytes)
             return hipSuccess;
+        if (ptr)
+            want += want / 4; // a buffer that grows once (ghost lists after a re-plan) will grow again: see DeviceBuffer
         release();
         hipError_t e = hipMalloc(&ptr, want);
         if (e == hipSuccess)

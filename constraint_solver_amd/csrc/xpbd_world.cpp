@@ -64,7 +64,10 @@ int set_error(int code, const char *fmt, ...)
 
 namespace {
 
-// A device allocation that only ever grows.
+// A device allocation that only ever grows.  The first request is served exactly (most buffers are sized by the body
+// count and never change); a buffer that has to GROW takes a quarter more than asked: the pair, neighbour and manifold
+// buffers follow the pair count of the frame, which creeps up frame after frame while a pile settles, and every
+// hipFree + hipMalloc of a block of ~100 MB stalls the stream for several hundred microseconds.
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -74,6 +77,7 @@ struct DeviceBuffer {
         if (want <= bytes)
             return hipSuccess;
         if (ptr) {
+            want += want / 4;
             hipError_t e = hipFree(ptr);
             ptr = nullptr;
             bytes = 0;
