@@ -30,13 +30,42 @@ __device__ __forceinline__ long long total_key(double v)
     return i ^ (long long)((unsigned long long)(i >> 63) >> 1);
 }
 
-// (value, index) reductions over `width` consecutive lanes (a power of two; xor offsets < width stay inside
-// the aligned group).
+// Value of `v` on the calling lane's PARTNER of reduction level `off` (a power of two).  Levels 1 and 2 are the xor
+// partners (DPP quad_perm), 4 and 8 the MIRROR partners inside the aligned 8 / 16 lanes (DPP row_half_mirror / row_mirror:
+// lane i <-> 7 - i, 15 - i).  Run over off = W/2 ... 1 the levels still connect all W lanes of an aligned group -- a
+// mirror flips the level's bit and all lower ones, which the lower levels flip back -- and a DPP move is one VALU
+// instruction where __shfl_xor is an address computation plus a ds_bpermute round trip through the LDS crossbar
+// (the narrowphase kernels are chains of such reductions).  Levels 16 and 32 cross the DPP rows: ds_bpermute.
+// Only for all-reductions whose combine does not depend on the pairing: min / max with a total-order tie-break.
+__device__ __forceinline__ int partner_i32(int v, uint32_t off)
+{
+    switch (off) {
+    case 1:
+        return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); // quad_perm [1, 0, 3, 2]
+    case 2:
+        return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); // quad_perm [2, 3, 0, 1]
+    case 4:
+        return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    case 8:
+        return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); // row_mirror
+    default:
+        return __shfl_xor(v, (int)off, 64);
+    }
+}
+__device__ __forceinline__ uint32_t partner(uint32_t v, uint32_t off) { return (uint32_t)partner_i32((int)v, off); }
+__device__ __forceinline__ long long partner(long long v, uint32_t off)
+{
+    const int lo = partner_i32((int)(unsigned long long)v, off), hi = partner_i32((int)((unsigned long long)v >> 32), off);
+    return (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double partner(double v, uint32_t off) { return __longlong_as_double(partner(__double_as_longlong(v), off)); }
+
+// (value, index) all-reductions over `width` consecutive lanes (a power of two, aligned): every lane ends with the result.
 __device__ __forceinline__ void reduce_max_first(double &v, uint32_t &idx, uint32_t width)
 {
     for (uint32_t off = width >> 1; off; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(idx, off, 64);
+        const double ov = partner(v, off);
+        const uint32_t oi = partner(idx, off);
         if (ov > v || (ov == v && oi < idx)) {
             v = ov;
             idx = oi;
@@ -47,8 +76,8 @@ __device__ __forceinline__ void reduce_max_first(double &v, uint32_t &idx, uint3
 __device__ __forceinline__ void reduce_min_first(double &v, uint32_t &idx, uint32_t width)
 {
     for (uint32_t off = width >> 1; off; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const uint32_t oi = __shfl_xor(idx, off, 64);
+        const double ov = partner(v, off);
+        const uint32_t oi = partner(idx, off);
         if (ov < v || (ov == v && oi < idx)) {
             v = ov;
             idx = oi;

@@ -91,14 +91,16 @@ __device__ __forceinline__ MVert minkowski_support(const Verts &s, uint32_t na, 
         }
     }
     for (uint32_t off = H / 2; off; off >>= 1) { // maximum, HIGHEST index on ties
-        const long long ok = __shfl_xor(key, off, 64);
-        const uint32_t oi = __shfl_xor(idx, off, 64);
+        const long long ok = partner(key, off);
+        const uint32_t oi = partner(idx, off);
         if (ok > key || (ok == key && oi > idx)) {
             key = ok;
             idx = oi;
         }
     }
-    const uint32_t ia = __shfl(idx, 0, L), ib = __shfl(idx, H, L);
+    // every lane of a half holds its half's result; the level-H partner is in the other half
+    const uint32_t other = partner(idx, H);
+    const uint32_t ia = half ? other : idx, ib = half ? idx : other;
     const Vec3 a = ld3(s.wa, ia), b = ld3(s.wb, ib);
     return MVert{a - b, a, b, ia, ib};
 }
@@ -207,8 +209,8 @@ __device__ __forceinline__ uint32_t closest_face(const GjkLds &s, uint32_t nf, u
             bi = f;
         }
     for (uint32_t off = 32; off; off >>= 1) {
-        const double od = __shfl_xor(bd, off, 64);
-        const uint32_t oi = __shfl_xor(bi, off, 64);
+        const double od = partner(bd, off);
+        const uint32_t oi = partner(bi, off);
         if (od < bd || (od == bd && oi < bi)) {
             bd = od;
             bi = oi;
@@ -784,8 +786,8 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
                 bi = f;
             }
         for (uint32_t off = L / 2; off; off >>= 1) {
-            const double od = __shfl_xor(bd, off, 64);
-            const uint32_t oi = __shfl_xor(bi, off, 64);
+            const double od = partner(bd, off);
+            const uint32_t oi = partner(bi, off);
             if (od < bd || (od == bd && oi < bi)) {
                 bd = od;
                 bi = oi;

@@ -164,8 +164,11 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
         }
     }
     reduce_max_first(fdist, fidx, H);
-    const double qa = __shfl(fdist, 0, L), qb = __shfl(fdist, H, L);
-    const uint32_t face_a = __shfl(fidx, 0, L), face_b = __shfl(fidx, H, L);
+    // every lane of a half holds its half's result; the level-H partner is in the other half
+    const double fdist_other = partner(fdist, H);
+    const uint32_t fidx_other = partner(fidx, H);
+    const double qa = half ? fdist_other : fdist, qb = half ? fdist : fdist_other;
+    const uint32_t face_a = half ? fidx_other : fidx, face_b = half ? fidx : fidx_other;
     if (qa >= 0.0 || qb >= 0.0 || face_a == kNone || face_b == kNone) {
         if (lane == 0)
             m->n_points = 0;
