@@ -50,6 +50,10 @@ struct GjkLds : GjkVerts {
     // EPA iteration (all zero in between, zeroed once per workgroup): an edge a -> b of a visible face is on the horizon iff
     // ve[b][a] == 0 -- one LDS read instead of a search through all faces (which made an iteration O(faces^2) per lane).
     uint8_t ve[kMaxEpaVerts][kMaxEpaVerts + 4];
+    // the horizon of the current iteration: directed edges a -> b in canonical order ((visible face, edge) ascending); lane q
+    // then builds the new face over edge q -- one make_face (a cross product, a square root, a division) per lane instead
+    // of up to three per visible face one after the other
+    uint8_t he[kMaxEpaFaces][2];
 };
 
 #ifdef XPBD_GJK_TIMING
@@ -634,18 +638,24 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         if (ne == 0 || keep + ne > kMaxEpaFaces)
             break; // numerical dead end or out of room: report the best face found so far
 
-        // pull my faces into registers, then rewrite the face table
+        // pull my surviving faces into registers, list the horizon, then rewrite the face table
         Face mine[2];
-        uint32_t edge_a[2][3], edge_b[2][3];
         for (uint32_t w = 0; w < 2; ++w) {
             const uint32_t k = w ? f1 : f0;
-            if (k < nf) {
-                mine[w].i0 = s.fi[k][0], mine[w].i1 = s.fi[k][1], mine[w].i2 = s.fi[k][2];
+            if (k >= nf)
+                continue;
+            mine[w].i0 = s.fi[k][0], mine[w].i1 = s.fi[k][1], mine[w].i2 = s.fi[k][2];
+            if (w ? vis1 : vis0) {
+                const uint32_t ea[3] = {mine[w].i0, mine[w].i1, mine[w].i2}, eb[3] = {mine[w].i1, mine[w].i2, mine[w].i0};
+                uint32_t q = w ? epos1 : epos0;
+                for (uint32_t e = 0; e < 3; ++e)
+                    if (hz[w] & (1u << e)) {
+                        s.he[q][0] = (uint8_t)ea[e], s.he[q][1] = (uint8_t)eb[e];
+                        ++q;
+                    }
+            } else {
                 mine[w].n = ld3(s.fn, k);
                 mine[w].dist = s.fd[k];
-                edge_a[w][0] = mine[w].i0, edge_b[w][0] = mine[w].i1;
-                edge_a[w][1] = mine[w].i1, edge_b[w][1] = mine[w].i2;
-                edge_a[w][2] = mine[w].i2, edge_b[w][2] = mine[w].i0;
             }
         }
         if (lane == 0) {
@@ -659,14 +669,10 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         if (f1 < nf && !vis1)
             store_face(s, kpos1, mine[1]);
         bool bad = false;
-        for (uint32_t w = 0; w < 2; ++w) {
-            uint32_t slot = keep + (w ? epos1 : epos0);
-            for (uint32_t e = 0; e < 3; ++e)
-                if (hz[w] & (1u << e)) {
-                    const Face f = make_face(s, edge_a[w][e], edge_b[w][e], nv, kNone);
-                    store_face(s, slot++, f);
-                    bad |= !f.ok;
-                }
+        for (uint32_t q = lane; q < ne; q += 64) { // the new faces over the horizon edges, one per lane
+            const Face f = make_face(s, s.he[q][0], s.he[q][1], nv, kNone);
+            store_face(s, keep + q, f);
+            bad |= !f.ok;
         }
         nf = keep + ne;
         ++nv;
@@ -741,6 +747,7 @@ struct EpaSubLds : GjkVertsT<kSubVerts> {
     double fn[kSubPolyFaces][3];
     double fd[kSubPolyFaces];
     uint8_t ve[kSubPolyVerts][kSubPolyVerts + 4];
+    uint8_t he[kSubPolyFaces][2]; // the horizon of the current iteration (see GjkLds)
 };
 
 template <uint32_t L>
@@ -888,13 +895,25 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         if (keep + ne > kSubPolyFaces)
             return false;
 
-        // pull my faces into registers, then rewrite the face table in the canonical order
+        // pull my surviving faces into registers, list the horizon (my horizon edges come after those of all lower faces,
+        // in edge order), then rewrite the face table in the canonical order
         Face mine[R];
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const uint32_t f = lane + L * j;
-            if (f < nf) {
-                mine[j].i0 = s.fi[f][0], mine[j].i1 = s.fi[f][1], mine[j].i2 = s.fi[f][2];
+            if (f >= nf)
+                continue;
+            mine[j].i0 = s.fi[f][0], mine[j].i1 = s.fi[f][1], mine[j].i2 = s.fi[f][2];
+            if (my_vis[j]) {
+                const unsigned long long below = (1ull << f) - 1ull;
+                uint32_t q = (uint32_t)(__popcll(edge_mask[0] & below) + __popcll(edge_mask[1] & below) + __popcll(edge_mask[2] & below));
+                const uint32_t ea[3] = {mine[j].i0, mine[j].i1, mine[j].i2}, eb[3] = {mine[j].i1, mine[j].i2, mine[j].i0};
+                for (uint32_t e = 0; e < 3; ++e)
+                    if (hz[j] & (1u << e)) {
+                        s.he[q][0] = (uint8_t)ea[e], s.he[q][1] = (uint8_t)eb[e];
+                        ++q;
+                    }
+            } else {
                 mine[j].n = ld3(s.fn, f);
                 mine[j].dist = s.fd[f];
             }
@@ -905,26 +924,17 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
             st3(s.vb, nv, pnt.b);
         }
         __syncthreads();
-        bool bad = false;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const uint32_t f = lane + L * j;
-            if (f >= nf)
-                continue;
-            const unsigned long long below = (1ull << f) - 1ull;
-            if (!my_vis[j]) {
-                store_face(s, (uint32_t)__popcll(kept & below), mine[j]);
-                continue;
-            }
-            // my horizon edges come after those of all lower faces, in edge order
-            uint32_t slot = keep + (uint32_t)(__popcll(edge_mask[0] & below) + __popcll(edge_mask[1] & below) + __popcll(edge_mask[2] & below));
-            const uint32_t ea[3] = {mine[j].i0, mine[j].i1, mine[j].i2}, eb[3] = {mine[j].i1, mine[j].i2, mine[j].i0};
-            for (uint32_t e = 0; e < 3; ++e)
-                if (hz[j] & (1u << e)) {
-                    const Face nfce = make_face(s, ea[e], eb[e], nv, kNone);
-                    store_face(s, slot++, nfce);
-                    bad |= !nfce.ok;
-                }
+            if (f < nf && !my_vis[j])
+                store_face(s, (uint32_t)__popcll(kept & ((1ull << f) - 1ull)), mine[j]);
+        }
+        bool bad = false;
+        for (uint32_t q = lane; q < ne; q += L) { // the new faces over the horizon edges, one per lane
+            const Face nfce = make_face(s, s.he[q][0], s.he[q][1], nv, kNone);
+            store_face(s, keep + q, nfce);
+            bad |= !nfce.ok;
         }
         nf = keep + ne;
         ++nv;
