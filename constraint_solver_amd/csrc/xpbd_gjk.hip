@@ -42,8 +42,9 @@ struct GjkVertsT {
 using GjkVerts = GjkVertsT<kMaxV>;
 
 struct GjkLds : GjkVerts {
-    double vw[kMaxEpaVerts][3], va[kMaxEpaVerts][3], vb[kMaxEpaVerts][3];      // polytope vertices + witnesses
-    uint32_t fi[kMaxEpaFaces][3];                                              // faces: vertex indices (outward winding)
+    double vw[kMaxEpaVerts][3];                                                // polytope vertices w = wa[via] - wb[vib]
+    uint8_t via[kMaxEpaVerts], vib[kMaxEpaVerts];                              // their witnesses, as vertex indices
+    uint32_t fi[kMaxEpaFaces];                                                 // faces: vertex indices (outward winding), a byte each
     double fn[kMaxEpaFaces][3];                                                //        unit normal
     double fd[kMaxEpaFaces];                                                   //        distance of the plane from the origin
     // ve[a][b] != 0: some face that SEES the new point holds the directed edge a -> b.  Set and cleared again inside every
@@ -164,6 +165,8 @@ struct Face {
     double dist;
     bool ok;
 };
+// vertex e (0..2; 3 = vertex 0 again) of a face's packed index word
+__device__ __forceinline__ uint32_t face_vertex(uint32_t packed, uint32_t e) { return (packed >> (8 * (e == 3 ? 0 : e))) & 0xFFu; }
 
 // Face (i0, i1, i2) of the polytope.  `opposite` = a vertex known to lie behind the face (the fourth vertex of the first
 // tetrahedron): the winding is flipped so that the normal points away from it.  kNone = trust the winding: a new face
@@ -197,7 +200,7 @@ __device__ __forceinline__ Face make_face(const S &s, uint32_t i0, uint32_t i1, 
 template <class S>
 __device__ __forceinline__ void store_face(S &s, uint32_t slot, const Face &f)
 {
-    s.fi[slot][0] = f.i0, s.fi[slot][1] = f.i1, s.fi[slot][2] = f.i2;
+    s.fi[slot] = f.i0 | (f.i1 << 8) | (f.i2 << 16);
     st3(s.fn, slot, f.n);
     s.fd[slot] = f.dist;
 }
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
 // face normal of one of the bodies (the face of A most aligned with n, or the face of B most aligned with -n, within
 // kFaceAlign) that face becomes the reference face of a clipped face contact exactly as in the SAT (A on ties); any
 // other normal -- an edge-edge contact -- and a clip that leaves no point below the reference plane keep the one point.
-// The clipper's polygons and reference face reuse the polytope's vertex rows (vw / va / vb): the expansion is over.
+// The clipper's polygons and reference face reuse the polytope's vertex rows and face normals: the expansion is over.
 constexpr double kFaceAlign = 0.999; // cosine: 2.6 degrees
 
 template <uint32_t L, class S>
@@ -450,19 +453,19 @@ __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const Sh
                                          ContactManifold *__restrict__ mf, uint32_t lane)
 {
     constexpr uint32_t P = L < 16 ? L : 16;
-    static_assert(sizeof(s.vw) >= P * 3 * sizeof(double) && sizeof(s.vb) >= kMaxFaceVerts * 3 * sizeof(double),
-                  "the clipper reuses the polytope's vertex rows");
+    static_assert(sizeof(s.vw) >= P * 3 * sizeof(double) && sizeof(s.fn) >= (P + kMaxFaceVerts) * 3 * sizeof(double),
+                  "the clipper reuses the polytope's vertex rows and face normals");
     const Vec3 nrm = ld3(s.fn, best);
     Vec3 pa{0.0, 0.0, 0.0}, pb{0.0, 0.0, 0.0};
     if (lane == 0) {
-        const uint32_t i0 = s.fi[best][0], i1 = s.fi[best][1], i2 = s.fi[best][2];
+        const uint32_t i0 = face_vertex(s.fi[best], 0), i1 = face_vertex(s.fi[best], 1), i2 = face_vertex(s.fi[best], 2);
         const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
         const Vec3 v0 = ld3(s.vw, i1) - aw, v1 = ld3(s.vw, i2) - aw, v2 = proj - aw;
         const double d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
         const double denom = d00 * d11 - d01 * d01;
         const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
-        pa = ld3(s.va, i0) * bu + ld3(s.va, i1) * bv + ld3(s.va, i2) * bw;
-        pb = ld3(s.vb, i0) * bu + ld3(s.vb, i1) * bv + ld3(s.vb, i2) * bw;
+        pa = ld3(s.wa, s.via[i0]) * bu + ld3(s.wa, s.via[i1]) * bv + ld3(s.wa, s.via[i2]) * bw;
+        pb = ld3(s.wb, s.vib[i0]) * bu + ld3(s.wb, s.vib[i1]) * bv + ld3(s.wb, s.vib[i2]) * bw;
         if (r) {
             r->depth = best_dist;
             r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
@@ -498,7 +501,7 @@ __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const Sh
     const uint32_t ref = align[0] >= align[1] ? 0u : 1u; // reference body: 0 = A, 1 = B
     if ((align[0] > align[1] ? align[0] : align[1]) >= kFaceAlign) // group-uniform
         n_out = face_contact_group<L, P>(t, ref ? db : da, ref ? da : db, ref ? fb : fa, ref ? fa : fb, face[ref], ref ? s.wb : s.wa,
-                                         ref ? s.wa : s.wb, s.vw, s.va, s.vb, mf, lane, iface);
+                                         ref ? s.wa : s.wb, s.vw, s.fn, s.fn + P, mf, lane, iface);
     if (lane != 0)
         return;
     mf->separation = -best_dist;
@@ -544,8 +547,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         const uint32_t va = (uint32_t)(seed >> (8 * lane)) & 0xFFu, vb = (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu;
         const Vec3 a = ld3(s.wa, va), bb = ld3(s.wb, vb);
         st3(s.vw, lane, a - bb);
-        st3(s.va, lane, a);
-        st3(s.vb, lane, bb);
+        s.via[lane] = (uint8_t)va, s.vib[lane] = (uint8_t)vb;
     }
     __syncthreads();
     uint32_t nv = 4, nf = 4;
@@ -577,8 +579,9 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 
         // visibility of "my" two faces (lane, lane + 64); the masks are wave-uniform
         const uint32_t f0 = lane, f1 = lane + 64;
-        const bool vis0 = f0 < nf && dot(ld3(s.fn, f0), pnt.w - ld3(s.vw, s.fi[f0][0])) > -kEpaCoplanar;
-        const bool vis1 = f1 < nf && dot(ld3(s.fn, f1), pnt.w - ld3(s.vw, s.fi[f1][0])) > -kEpaCoplanar;
+        const uint32_t pk[2] = {f0 < nf ? s.fi[f0] : 0u, f1 < nf ? s.fi[f1] : 0u}; // my faces' vertex indices, read once
+        const bool vis0 = f0 < nf && dot(ld3(s.fn, f0), pnt.w - ld3(s.vw, face_vertex(pk[0], 0))) > -kEpaCoplanar;
+        const bool vis1 = f1 < nf && dot(ld3(s.fn, f1), pnt.w - ld3(s.vw, face_vertex(pk[1], 0))) > -kEpaCoplanar;
         const unsigned long long mask0 = __ballot(vis0), mask1 = __ballot(vis1);
 
         // horizon test of my faces' edges: a->b is on the horizon iff no other VISIBLE face holds b->a (a face never holds
@@ -586,30 +589,23 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         // mark their directed edges in `ve`, every visible face's edge then looks its reverse up, and the marks are
         // cleared again before anything can leave the loop.
         uint32_t hz[2] = {0, 0};
-        for (uint32_t w = 0; w < 2; ++w) {
-            const uint32_t k = w ? f1 : f0;
+        for (uint32_t w = 0; w < 2; ++w)
             if (w ? vis1 : vis0)
                 for (uint32_t e = 0; e < 3; ++e)
-                    s.ve[s.fi[k][e]][s.fi[k][e == 2 ? 0 : e + 1]] = 1;
-        }
+                    s.ve[face_vertex(pk[w], e)][face_vertex(pk[w], e + 1)] = 1;
         __syncthreads();
         for (uint32_t w = 0; w < 2; ++w) {
-            const uint32_t k = w ? f1 : f0;
             if (!(w ? vis1 : vis0))
                 continue;
-            for (uint32_t e = 0; e < 3; ++e) {
-                const uint32_t ea = s.fi[k][e], eb = s.fi[k][e == 2 ? 0 : e + 1];
-                if (!s.ve[eb][ea])
+            for (uint32_t e = 0; e < 3; ++e)
+                if (!s.ve[face_vertex(pk[w], e + 1)][face_vertex(pk[w], e)])
                     hz[w] |= 1u << e;
-            }
         }
         __syncthreads();
-        for (uint32_t w = 0; w < 2; ++w) {
-            const uint32_t k = w ? f1 : f0;
+        for (uint32_t w = 0; w < 2; ++w)
             if (w ? vis1 : vis0)
                 for (uint32_t e = 0; e < 3; ++e)
-                    s.ve[s.fi[k][e]][s.fi[k][e == 2 ? 0 : e + 1]] = 0;
-        }
+                    s.ve[face_vertex(pk[w], e)][face_vertex(pk[w], e + 1)] = 0;
         // canonical slots: surviving faces keep their order; horizon edges ordered by (face, edge)
         // (exclusive prefix sums over the lanes of 0/1 flags and of 3-bit edge masks: a ballot per bit and a popcount
         // of the lanes below, instead of a six-step shuffle scan each)
@@ -644,7 +640,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
             const uint32_t k = w ? f1 : f0;
             if (k >= nf)
                 continue;
-            mine[w].i0 = s.fi[k][0], mine[w].i1 = s.fi[k][1], mine[w].i2 = s.fi[k][2];
+            mine[w].i0 = face_vertex(pk[w], 0), mine[w].i1 = face_vertex(pk[w], 1), mine[w].i2 = face_vertex(pk[w], 2);
             if (w ? vis1 : vis0) {
                 const uint32_t ea[3] = {mine[w].i0, mine[w].i1, mine[w].i2}, eb[3] = {mine[w].i1, mine[w].i2, mine[w].i0};
                 uint32_t q = w ? epos1 : epos0;
@@ -660,8 +656,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         }
         if (lane == 0) {
             st3(s.vw, nv, pnt.w);
-            st3(s.va, nv, pnt.a);
-            st3(s.vb, nv, pnt.b);
+            s.via[nv] = (uint8_t)pnt.ia, s.vib[nv] = (uint8_t)pnt.ib;
         }
         __syncthreads();
         if (f0 < nf && !vis0)
@@ -742,8 +737,9 @@ constexpr uint32_t kSubRows = kSubPolyVerts < 16 ? 16 : kSubPolyVerts; // the cl
 constexpr uint32_t kSubPolyFaces = 2 * kSubPolyVerts - 4; // Euler: a closed triangulated polytope with V vertices has 2 V - 4 faces
 
 struct EpaSubLds : GjkVertsT<kSubVerts> {
-    double vw[kSubRows][3], va[kSubRows][3], vb[kSubRows][3]; // (then the clipper's polygons and reference face)
-    uint32_t fi[kSubPolyFaces][3];
+    double vw[kSubRows][3];                  // polytope vertices w = wa[via] - wb[vib] (then a clipper polygon)
+    uint8_t via[kSubRows], vib[kSubRows];    // their witnesses, as vertex indices
+    uint32_t fi[kSubPolyFaces];
     double fn[kSubPolyFaces][3];
     double fd[kSubPolyFaces];
     uint8_t ve[kSubPolyVerts][kSubPolyVerts + 4];
@@ -810,8 +806,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         const uint32_t va = (uint32_t)(seed >> (8 * lane)) & 0xFFu, vb = (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu;
         const Vec3 a = ld3(s.wa, va), bb = ld3(s.wb, vb);
         st3(s.vw, lane, a - bb);
-        st3(s.va, lane, a);
-        st3(s.vb, lane, bb);
+        s.via[lane] = (uint8_t)va, s.vib[lane] = (uint8_t)vb;
     }
     __syncthreads();
     uint32_t nv = 4, nf = 4;
@@ -845,11 +840,13 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 
         // visibility of my faces f = lane + L * j; bit f of `vis` for the whole group
         bool my_vis[R];
+        uint32_t pk[R]; // my faces' vertex indices, read once
         unsigned long long vis = 0, valid = 0;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const uint32_t f = lane + L * j;
-            my_vis[j] = f < nf && dot(ld3(s.fn, f), pnt.w - ld3(s.vw, s.fi[f][0])) > -kEpaCoplanar;
+            pk[j] = f < nf ? s.fi[f] : 0u;
+            my_vis[j] = f < nf && dot(ld3(s.fn, f), pnt.w - ld3(s.vw, face_vertex(pk[j], 0))) > -kEpaCoplanar;
             vis |= group_ballot<L>(my_vis[j]) << (L * j);
             valid |= group_ballot<L>(f < nf) << (L * j);
         }
@@ -857,32 +854,26 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         // marks are cleared again (see epa_pair)
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j)
-            if (my_vis[j]) {
-                const uint32_t f = lane + L * j;
+            if (my_vis[j])
                 for (uint32_t e = 0; e < 3; ++e)
-                    s.ve[s.fi[f][e]][s.fi[f][e == 2 ? 0 : e + 1]] = 1;
-            }
+                    s.ve[face_vertex(pk[j], e)][face_vertex(pk[j], e + 1)] = 1;
         __syncthreads();
         uint32_t hz[R];
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             hz[j] = 0;
-            if (my_vis[j]) {
-                const uint32_t f = lane + L * j;
+            if (my_vis[j])
                 for (uint32_t e = 0; e < 3; ++e)
-                    if (!s.ve[s.fi[f][e == 2 ? 0 : e + 1]][s.fi[f][e]])
+                    if (!s.ve[face_vertex(pk[j], e + 1)][face_vertex(pk[j], e)])
                         hz[j] |= 1u << e;
-            }
         }
         __syncthreads();
         unsigned long long edge_mask[3] = {0, 0, 0}; // bit f: edge e of face f is on the horizon
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            if (my_vis[j]) {
-                const uint32_t f = lane + L * j;
+            if (my_vis[j])
                 for (uint32_t e = 0; e < 3; ++e)
-                    s.ve[s.fi[f][e]][s.fi[f][e == 2 ? 0 : e + 1]] = 0;
-            }
+                    s.ve[face_vertex(pk[j], e)][face_vertex(pk[j], e + 1)] = 0;
 #pragma unroll
             for (uint32_t e = 0; e < 3; ++e)
                 edge_mask[e] |= group_ballot<L>((hz[j] >> e) & 1u) << (L * j);
@@ -903,7 +894,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
             const uint32_t f = lane + L * j;
             if (f >= nf)
                 continue;
-            mine[j].i0 = s.fi[f][0], mine[j].i1 = s.fi[f][1], mine[j].i2 = s.fi[f][2];
+            mine[j].i0 = face_vertex(pk[j], 0), mine[j].i1 = face_vertex(pk[j], 1), mine[j].i2 = face_vertex(pk[j], 2);
             if (my_vis[j]) {
                 const unsigned long long below = (1ull << f) - 1ull;
                 uint32_t q = (uint32_t)(__popcll(edge_mask[0] & below) + __popcll(edge_mask[1] & below) + __popcll(edge_mask[2] & below));
@@ -920,8 +911,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         }
         if (lane == 0) {
             st3(s.vw, nv, pnt.w);
-            st3(s.va, nv, pnt.a);
-            st3(s.vb, nv, pnt.b);
+            s.via[nv] = (uint8_t)pnt.ia, s.vib[nv] = (uint8_t)pnt.ib;
         }
         __syncthreads();
 #pragma unroll
@@ -955,8 +945,13 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 // Four hits per wave (16 lanes each), grid-stride over the hit list; hits that outgrow the small polytope are appended to
 // `overflow` (one atomic each: rare) for k_epa_pairs.  Block 0 zeroes the counter the NEXT k_gjk_pairs launch appends
 // through -- the overflow pass (launched after this kernel with the same pointer) only zeroes it again.
-template <uint32_t L, bool STAGED>
-__global__ void __launch_bounds__(64) k_epa_pairs_sub(BodyArrays b, PolytopeTables t_global, const double *__restrict__ frames,
+// The kernel is a chain of LDS round trips and cross-lane reductions per hit, so what counts is how many hits a CU has in
+// flight: 168 VGPRs (3 waves per SIMD; the compiler takes 180 when left alone) and 12.7 KB of LDS per workgroup -- witness
+// points as vertex indices, a face's three vertex indices in one word, and no staged shape tables (they cost 2 KB and
+// one workgroup per CU: A/B on the mixed pile 1.78e8 -> 1.88e8 body-substeps/s without them) -- give 12 workgroups per CU.
+template <uint32_t L>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                       const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
                                                       ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
                                                       uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
@@ -965,8 +960,6 @@ __global__ void __launch_bounds__(64) k_epa_pairs_sub(BodyArrays b, PolytopeTabl
 {
     constexpr uint32_t PW = 64 / L;
     __shared__ EpaSubLds s_all[PW];
-    __shared__ StagedTables staged;
-    const PolytopeTables t = stage_tables<STAGED>(t_global, staged);
     EpaSubLds &s = s_all[threadIdx.x / L];
     const uint32_t lane = threadIdx.x % L;
     for (uint32_t k = lane; k < sizeof(s.ve) / 4; k += L)
@@ -1076,12 +1069,8 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         if (hipError_t e = hipMemsetAsync(overflow_count, 0, 4, stream))
             return e;
         const uint32_t groups = (n_pairs + 3) / 4;
-        if (staged)
-            hipLaunchKernelGGL((k_epa_pairs_sub<16, true>), dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames,
-                               pairs, out, manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
-        else
-            hipLaunchKernelGGL((k_epa_pairs_sub<16, false>), dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames,
-                               pairs, out, manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+        hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
+                           manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
         hipLaunchKernelGGL(k_epa_pairs, dim3(n_pairs < 256 ? n_pairs : 256), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds,
                            overflow_count, 1u, next, overflow, n_pairs, seeds);
         return hipGetLastError();
