@@ -368,6 +368,37 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
     return result
 
 
+def contacts_in_child_processes(args, rank):
+    """N > 1: the contacts sub-results run the native multi-GPU world (RCCL all-gathers of its own).  Whatever happens in
+    there -- a communicator that never forms, a rank lost, a crash inside the library -- the headline line must still come
+    out, so every rank runs them in a CHILD process (same ranks, a rendezvous port of its own) and waits for it with a
+    time limit; rank 0 takes the sub-results from its child's stdout.  The parent's own process group stays idle meanwhile."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # rank 0 of the children hosts their store itself
+    cmd = [sys.executable, os.path.abspath(__file__), "--contacts-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--substeps", str(args.substeps), "--seed", str(args.seed), "--backend", args.backend]
+    if args.single_device:
+        cmd.append("--single-device")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                             stderr=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    try:
+        out, err = child.communicate(timeout=args.contacts_timeout)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        return {"error": "timed out after %d s" % args.contacts_timeout}
+    if rank != 0:
+        return {}
+    for line in reversed((out or "").strip().splitlines()):
+        try:
+            return json.loads(line)["contacts"]
+        except (ValueError, KeyError):
+            continue
+    return {"error": "child exited with code %d: %s" % (child.returncode, (err or "").strip()[-400:])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,6 +435,8 @@ def main():
                     help="process-group backend for the barrier/MAX reduction (gloo: rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--contacts-child", action="store_true", help=argparse.SUPPRESS)   # N > 1: see contacts_in_child_processes
+    ap.add_argument("--force-contacts", action="store_true", help=argparse.SUPPRESS)   # rehearsal of the child's failure path
     args = ap.parse_args()
 
     import numpy as np
@@ -422,7 +455,7 @@ def main():
         if args.backend != "gloo":
             raise SystemExit("--single-device shares one GPU between ranks; RCCL refuses that, use --backend gloo")
         local_rank = 0
-    if args.single_device and world_size > 1:
+    if args.single_device and world_size > 1 and not (args.force_contacts or args.contacts_child):
         args.no_contacts = True          # the contacts sub-results exchange halos over RCCL, which refuses two ranks on one device
     torch.cuda.set_device(local_rank)
     if world_size > 1:
@@ -456,6 +489,21 @@ def main():
         # the mixed piles keep shedding light tetrahedra at > 100 m/s ("Scenes"): several metres per frame,
         # beyond any halo margin worth having -- the sharded world would (rightly) refuse them with XPBD_E_HALO
         sub_runs = {k: v for k, v in sub_runs.items() if not k.startswith("mixed_pile")}
+    if args.contacts_child:
+        # N > 1: the sub-results of the default line, in a process group of their own (see contacts_in_child_processes)
+        subs = {}
+        for name, cfg in sub_runs.items():
+            try:
+                r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
+                                 steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=False, **cfg)
+            except capi.XpbdError as e:                     # e.g. XPBD_E_HALO in a scene that outruns its margin
+                r = {"error": str(e)}
+            subs[name] = r
+        if rank == 0:
+            print(json.dumps({"contacts": subs}), flush=True)
+        barrier()
+        dist.destroy_process_group()
+        return subs
     if args.only and args.only != "pinned":
         if args.only not in sub_runs:
             raise SystemExit("--only: one of pinned, %s" % ", ".join(sub_runs))
@@ -628,31 +676,16 @@ def main():
 
     # ---------------------------------------------------------------- the north-star workloads (extension)
     if not args.no_contacts and not args.only and mode == capi.MODE_FUSED:
-        subs = {}
         if world_size > 1:
-            # The sub-results run collectives of their own (the native multi-GPU world).  Should one of them hang -- a rank
-            # lost, a communicator that never forms -- the headline line must still come out: after this many seconds rank 0
-            # prints what it has and every rank leaves.
-            import signal
-
-            def give_up(signum, frame):
-                if rank == 0:
-                    subs["error"] = "timed out after %d s" % args.contacts_timeout
-                    result["contacts"] = subs
-                    print(json.dumps(result), flush=True)
-                os._exit(0)
-            signal.signal(signal.SIGALRM, give_up)
-            signal.alarm(args.contacts_timeout)
-        for name, cfg in sub_runs.items():
-            try:
-                r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
-                                 steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, **cfg)
-            except capi.XpbdError as e:                     # e.g. XPBD_E_HALO in a scene that outruns its margin
-                r = {"error": str(e)}
-            if rank == 0:
-                subs[name] = r
-        if world_size > 1:
-            signal.alarm(0)
+            subs = contacts_in_child_processes(args, rank)
+        else:
+            subs = {}
+            for name, cfg in sub_runs.items():
+                try:
+                    subs[name] = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
+                                              steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, **cfg)
+                except capi.XpbdError as e:
+                    subs[name] = {"error": str(e)}
         if rank == 0:
             result["contacts"] = subs
     if rank == 0:
