@@ -234,6 +234,8 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
     world.set_polytopes(capi.scene_polytopes(kind))
     world.set_contact_pad(pad)
     world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT)
+    world.set_sat_schedule({"auto": capi.SAT_SCHEDULE_AUTO, "one-pass": capi.SAT_SCHEDULE_ONE_PASS,
+                            "two-pass": capi.SAT_SCHEDULE_TWO_PASS}[args.sat_schedule])
     world.upload(state, shape_id)
     joints = chain_joints(capi, np, joints_n, count, pitch, scene_grid_width(capi, kind, total, total)) if joints_n else None
     if joints is not None:
@@ -422,6 +424,9 @@ def main():
                                                "with no extras and no CPU leg")
     ap.add_argument("--narrowphase", default="sat", choices=["sat", "gjk"],
                     help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (one point per pair)")
+    ap.add_argument("--sat-schedule", default="auto", choices=["auto", "one-pass", "two-pass"],
+                    help="contacts mode, SAT: pre-test inside the SAT kernel, or as a pass of its own (with the cached separating "
+                         "face axes) and the SAT over the survivors; auto = the library's choice.  Same results either way")
     ap.add_argument("--joints", type=int, default=0,
                     help="contacts mode: link bodies into chains of 5 along x with this many distance joints (4 per chain)")
     ap.add_argument("--local-shards", type=int, default=0,

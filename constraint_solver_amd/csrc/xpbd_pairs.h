@@ -87,10 +87,19 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 // counter per pair class), zero when idle; launch k appends through pair k & 1 and its consumer kernels zero pair
 // (k + 1) & 1 for the next launch (all launches of one world are stream-ordered).  `survivors`: n_pairs uint32; class 0
 // fills it from the front, class 1 from the back.
+//
+// `axis_cache` (n_pairs uint16, or null): the face axis that separated a pair the last time the SAT looked at it --
+// 0 = none, else 1 + 2 * face + (0: a face of A, 1: of B).  A pair of a settled pile that is separated by a face axis in
+// one substep is separated by the SAME axis in the next 99 times in 100 (scripts/separated_pair_census.py), and more
+// than half of a pile's neighbour pairs are such pairs.  The pre-test pass therefore evaluates the cached face query
+// first -- exactly the arithmetic the full SAT would do for that face, so the verdict "separated" is the SAT's own --
+// and answers the pair without sending it to the SAT at all; the SAT kernels refresh the entry on every exit.
+// The owner zeroes the cache whenever the pair list changes.
 struct SatScratch {
     uint32_t *counters;
     uint32_t *survivors;
     uint32_t calls;
+    uint16_t *axis_cache;
 };
 
 // The contact pipeline answers "no contact" for pairs whose tight bounding spheres are disjoint (the diagnostic entry
@@ -100,10 +109,12 @@ struct SatScratch {
 hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                             uint32_t n_pairs, Manifold *out, hipStream_t stream); // diagnostic: every pair, full query
 // The pre-test pass alone: answers the rejected pairs in `out`, appends the others to list.survivors and returns the
-// counter this launch appends through and the one the consumer kernel must zero for the next launch.
+// counter this launch appends through and the one the consumer kernel must zero for the next launch.  use_axis_cache:
+// also answer the pairs whose cached SAT face axis still separates them (only for a SAT consumer: "separated" is then the
+// SAT's own verdict; GJK's is not defined by face axes).
 hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
-                               hipStream_t stream);
+                               hipStream_t stream, bool use_axis_cache = false);
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, SatScratch *list,
                                hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form

@@ -114,7 +114,8 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 // the next one clipping).
 template <uint32_t L, class Lds, class M>
 __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
-                                         const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane)
+                                         const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane,
+                                         uint16_t *__restrict__ axis_cache = nullptr)
 {
     constexpr uint32_t H = L / 2;             // lanes per body in the two-sided stages
     constexpr uint32_t P = L < 16 ? L : 16;   // polygon capacity of the clipper: one vertex per lane, at most 16 (the
@@ -170,10 +171,15 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     const double qa = half ? fdist_other : fdist, qb = half ? fdist : fdist_other;
     const uint32_t face_a = half ? fidx_other : fidx, face_b = half ? fidx : fidx_other;
     if (qa >= 0.0 || qb >= 0.0 || face_a == kNone || face_b == kNone) {
-        if (lane == 0)
+        if (lane == 0) {
             m->n_points = 0;
+            if (axis_cache) // the face that separates the pair: the pre-test pass tries it first in the next substep
+                axis_cache[p] = (uint16_t)(qa >= 0.0 ? 1u + 2u * face_a : (qb >= 0.0 ? 2u + 2u * face_b : 0u));
+        }
         return;
     }
+    if (axis_cache && lane == 0)
+        axis_cache[p] = 0; // not separated by a face axis (any more)
 
     // ---- edge axes: (unique edge direction of A) x (unique edge direction of B), strided over the group ----
     // n = normalize(dA x dB) pointing from A's centroid to B's; separation = min_B n.b - max_A n.a.
@@ -379,11 +385,43 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(B
 // pass 25 us for 50 000 pairs); the order of a list is irrelevant, results go to out[p].
 constexpr uint32_t kPretestBlock = 1024;
 
+// The face query of ONE cached face (SatScratch::axis_cache) by one thread: does face `face` of body X (0 = A, 1 = B)
+// still separate pair p?  The arithmetic is that of sat_pair for this face -- the other body's vertices through its own
+// frame into world space and through the inverse of X's frame into X-local space, the LAST maximum of -n . v under the
+// total order, n . support - displacement -- so a "yes" here is the "separated" the full SAT would return.
+__device__ __forceinline__ bool cached_face_separates(const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
+                                                      const uint32_t *__restrict__ pairs, uint32_t p, uint32_t code)
+{
+    const uint32_t owner = (code - 1u) & 1u, face = (code - 1u) >> 1;
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
+    const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
+    const ShapeDesc da = t.desc[b.shape_id[ia]], db = t.desc[b.shape_id[ib]];
+    const ShapeDesc dx = owner ? db : da, dy = owner ? da : db;
+    if (face >= dx.n_faces || dy.n_verts == 0)
+        return false;
+    const Frame fy = owner ? fa : fb, fx_inv = inverse(owner ? fb : fa);
+    const double *pl = t.planes + 4 * (size_t)(dx.face0 + face);
+    const Vec3 n{pl[0], pl[1], pl[2]}, dir = -n;
+    Vec3 best{0.0, 0.0, 0.0};
+    long long best_key = 0;
+    for (uint32_t k = 0; k < dy.n_verts; ++k) { // support_last_max over the other body's vertices in X-local space
+        const double *v = t.verts + 3 * (size_t)(dy.vert0 + k);
+        const Vec3 w = fy * Vec3{v[0], v[1], v[2]};
+        const Vec3 local = fx_inv * w; // frames.0.inverse() * (frames.1 * p), :136-137
+        const long long key = total_key(dot(local, dir));
+        if (k == 0 || best_key <= key) {
+            best_key = key;
+            best = local;
+        }
+    }
+    return dot(n, best) - pl[3] >= 0.0;
+}
+
 template <bool CLASSES>
 __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                                 const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                                 ContactManifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
-                                                                uint32_t *__restrict__ survivors)
+                                                                uint32_t *__restrict__ survivors, const uint16_t *__restrict__ axis_cache)
 {
     constexpr uint32_t NC = CLASSES ? 2 : 1;
     __shared__ uint32_t wave_base[NC][kPretestBlock / 64 + 1];
@@ -392,6 +430,11 @@ __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, Po
     uint32_t cls = 0;
     if (p < n_pairs) {
         keep = tight_spheres_overlap(b, t, frames, pairs, p);
+        if (keep && axis_cache) {
+            const uint32_t code = axis_cache[p];
+            if (code && cached_face_separates(b, t, frames, pairs, p, code))
+                keep = false; // (the entry stays as it is)
+        }
         if (!keep)
             out[p].n_points = 0;
         else if (CLASSES) {
@@ -435,7 +478,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
                                                                                    const uint32_t *__restrict__ survivor_count,
                                                                                    uint32_t *__restrict__ next_survivor_counts,
                                                                                    const uint32_t *__restrict__ survivors, uint32_t back_n,
-                                                                                   ContactManifold *__restrict__ out)
+                                                                                   ContactManifold *__restrict__ out, uint16_t *__restrict__ axis_cache)
 {
     using Lds = typename SatLds<L, V>::Record;
     __shared__ Lds s_all[SatLds<L, V>::PW];
@@ -446,7 +489,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
         next_survivor_counts[threadIdx.x] = 0;
     if (k >= n)
         return;
-    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane);
+    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane, axis_cache);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -569,13 +612,13 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 
 hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
-                               hipStream_t stream)
+                               hipStream_t stream, bool use_axis_cache)
 {
     *count = list.counters + 2u * (list.calls & 1u);
     *next_count = list.counters + 2u * ((list.calls + 1u) & 1u);
     ++list.calls;
     hipLaunchKernelGGL(k_pair_pretest<false>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
-                       pairs, n_pairs, out, *count, list.survivors);
+                       pairs, n_pairs, out, *count, list.survivors, use_axis_cache ? list.axis_cache : nullptr);
     return hipGetLastError();
 }
 
@@ -590,16 +633,16 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         uint32_t *count = list->counters + 2u * (list->calls & 1u), *next = list->counters + 2u * ((list->calls + 1u) & 1u);
         ++list->calls;
         hipLaunchKernelGGL(k_pair_pretest<true>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
-                           frames, pairs, n_pairs, out, count, list->survivors);
+                           frames, pairs, n_pairs, out, count, list->survivors, list->axis_cache);
         for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,
-                               next, list->survivors, 0u, out);
+                               next, list->survivors, 0u, out, list->axis_cache);
         });
         for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs,
-                               count + 1, next, list->survivors, n_pairs, out);
+                               count + 1, next, list->survivors, n_pairs, out, list->axis_cache);
         });
         return hipGetLastError();
     }
@@ -608,8 +651,9 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
         if (list) { // pre-test pass, then the SAT over the survivors
             uint32_t *count = nullptr, *next = nullptr;
-            (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, out, *list, &count, &next, stream);
-            hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, 0u, out);
+            (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, out, *list, &count, &next, stream, true);
+            hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, 0u, out,
+                               list->axis_cache);
         } else {
             hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
         }
