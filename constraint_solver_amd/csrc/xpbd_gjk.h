@@ -32,10 +32,15 @@ constexpr uint32_t kEpaBlocks = 8192;   // grid of the EPA kernel (one wave per 
 constexpr uint32_t kHitSegments = 32;
 constexpr uint32_t kHitCounterStride = 32; // uint32: 128 bytes
 constexpr size_t gjk_counter_bytes() { return (size_t)2 * kHitSegments * kHitCounterStride * 4; }
+// `axis_cache` (3 doubles per pair, or null; needs the pre-test as a pass of its own): the direction whose support plane
+// proved a pair separated in its last query, zero = none.  The pre-test pass tries it before the pair is sent to GJK again
+// (semantics: og_gjk_epa_cached of the oracle -- in a settled pile most separated pairs stay separated by the same plane
+// from one substep to the next); every full query refreshes it, the owner zeroes it with every new pair list.
 struct GjkScratch {
     uint32_t *counters;
     void *pairs_scratch;
     uint32_t calls;
+    double *axis_cache;
 };
 size_t gjk_scratch_bytes(uint32_t n_pairs);
 

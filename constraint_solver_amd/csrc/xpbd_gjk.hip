@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
                                                   uint32_t *__restrict__ next_survivor_count,
                                                   GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds,
                                                   uint32_t *__restrict__ hit_counts, uint32_t *__restrict__ hits, uint32_t segment_capacity,
-                                                  unsigned long long *__restrict__ seeds)
+                                                  unsigned long long *__restrict__ seeds, double *__restrict__ axis_cache)
 {
 #ifdef XPBD_GJK_TIMING
     unsigned long long tick_ = clock64();
@@ -328,11 +328,13 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
         da = t.desc[sa], db = t.desc[sb];
     }
     bool usable = live && da.n_verts != 0 && db.n_verts != 0;
+    bool queried = live; // a pair the sphere pre-test rejects is not a query: its cached direction stays
     if (PRETEST && usable) {
         const double *ca = t.centroids + 3 * (size_t)sa, *cb = t.centroids + 3 * (size_t)sb;
         const Vec3 between = fb * Vec3{cb[0], cb[1], cb[2]} - fa * Vec3{ca[0], ca[1], ca[2]};
         const double reach = t.radii[sa] + t.radii[sb];
         usable = dot(between, between) < reach * reach;
+        queried = usable;
     }
     GJK_TICK(0); // input loads + pre-test
     if (usable)
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     int32_t status = 0;
     uint32_t gjk_iters = 0;
     MVert s0{}, s1{}, s2{}, s3{};
+    Vec3 separating{0.0, 0.0, 0.0}; // the direction whose support plane proves the pair separated (GjkScratch::axis_cache)
     if (usable) {
         const uint32_t na = da.n_verts, nb = db.n_verts;
         uint32_t n = 1;
@@ -365,6 +368,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
             const MVert pnt = minkowski_support<L>(s, na, nb, d, lane);
             if (!(dot(pnt.w, d) > 0.0)) { // separated (or just touching)
                 status = 0;
+                separating = d;
                 break;
             }
             if (n == 1) {
@@ -417,6 +421,10 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
         }
         if (manifolds && status != 1)
             manifolds[p].n_points = 0;
+        if (axis_cache && queried) {
+            double *c = axis_cache + 3 * (size_t)p;
+            c[0] = separating.x, c[1] = separating.y, c[2] = separating.z;
+        }
     }
     const bool hit = writer && status == 1;
     const unsigned long long hit_mask = __ballot(hit);
@@ -1033,12 +1041,16 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     const uint32_t *survivors = nullptr;
     uint32_t *survivor_count = nullptr, *next_survivor_count = nullptr;
     if (sphere_pretest && list && manifolds) { // two-pass form: the pre-test pass answers the rejected pairs
-        if (hipError_t e = launch_pair_pretest(b, t, frames, pairs, n_pairs, manifolds, *list, &survivor_count, &next_survivor_count, stream))
+        if (hipError_t e = launch_pair_pretest(b, t, frames, pairs, n_pairs, manifolds, *list, &survivor_count, &next_survivor_count, stream,
+                                               false, scratch.axis_cache))
             return e;
         survivors = list->survivors;
         sphere_pretest = false; // the survivors have passed it
     }
     const bool staged = t.n_shapes <= kStageShapes && t.total_verts <= kStageVerts;
+    // the cache is part of the pipeline's semantics, and the pre-test pass is where it is consulted: without that pass
+    // (the diagnostic entry point, or a caller that wants the pre-test inside the kernel) it is neither read nor written
+    double *const axis = survivors ? scratch.axis_cache : nullptr;
     uint32_t segment_capacity = 0;
     auto launch = [&](auto lanes, auto pretest) {
         constexpr uint32_t L = decltype(lanes)::value, V = L == 32 ? kMaxV : 16;
@@ -1047,10 +1059,10 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         segment_capacity = (grid.x + kHitSegments - 1) / kHitSegments * (64 / L); // what the workgroups of one segment can append
         if (staged)
             hipLaunchKernelGGL((k_gjk_pairs<L, V, P, true>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds);
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis);
         else
             hipLaunchKernelGGL((k_gjk_pairs<L, V, P, false>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds);
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis);
     };
     using std::integral_constant;
     // lanes per pair: XPBD_GJK_SMALL_LANES for shapes of at most 16 vertices (the simplex logic is replicated on every

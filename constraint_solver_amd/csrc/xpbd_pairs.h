@@ -111,10 +111,10 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
 // The pre-test pass alone: answers the rejected pairs in `out`, appends the others to list.survivors and returns the
 // counter this launch appends through and the one the consumer kernel must zero for the next launch.  use_axis_cache:
 // also answer the pairs whose cached SAT face axis still separates them (only for a SAT consumer: "separated" is then the
-// SAT's own verdict; GJK's is not defined by face axes).
+// SAT's own verdict; GJK's is not defined by face axes).  gjk_axis_cache: GjkScratch::axis_cache of a GJK consumer.
 hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
-                               hipStream_t stream, bool use_axis_cache = false);
+                               hipStream_t stream, bool use_axis_cache = false, const double *gjk_axis_cache = nullptr);
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, SatScratch *list,
                                hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form

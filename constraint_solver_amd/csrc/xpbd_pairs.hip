@@ -385,6 +385,35 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(B
 // pass 25 us for 50 000 pairs); the order of a list is irrelevant, results go to out[p].
 constexpr uint32_t kPretestBlock = 1024;
 
+// GjkScratch::axis_cache, one thread per pair: does the support plane of the cached direction d still separate the
+// pair?  og_direction_separates of the oracle: the support vertices are picked in each body's LOCAL space (d turned back
+// by the conjugate rotation, last maximum under the total order), only the two winners go to world space.
+__device__ __forceinline__ bool cached_direction_separates(const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
+                                                           const uint32_t *__restrict__ pairs, uint32_t p, Vec3 d)
+{
+    const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
+    const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
+    const ShapeDesc da = t.desc[b.shape_id[ia]], db = t.desc[b.shape_id[ib]];
+    if (da.n_verts == 0 || db.n_verts == 0)
+        return false;
+    auto support = [&](const ShapeDesc &ds, Vec3 dir) { // support_index: last maximum under the total order
+        Vec3 best{0.0, 0.0, 0.0};
+        long long best_key = 0;
+        for (uint32_t k = 0; k < ds.n_verts; ++k) {
+            const double *v = t.verts + 3 * (size_t)(ds.vert0 + k);
+            const Vec3 x{v[0], v[1], v[2]};
+            const long long key = total_key(dot(x, dir));
+            if (k == 0 || best_key <= key) {
+                best_key = key;
+                best = x;
+            }
+        }
+        return best;
+    };
+    const Vec3 a = fa * support(da, conjugate(fa.rotation) * d), bb = fb * support(db, conjugate(fb.rotation) * (-d));
+    return !(dot(a - bb, d) > 0.0);
+}
+
 // The face query of ONE cached face (SatScratch::axis_cache) by one thread: does face `face` of body X (0 = A, 1 = B)
 // still separate pair p?  The arithmetic is that of sat_pair for this face -- the other body's vertices through its own
 // frame into world space and through the inverse of X's frame into X-local space, the LAST maximum of -n . v under the
@@ -421,7 +450,8 @@ template <bool CLASSES>
 __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                                 const uint32_t *__restrict__ pairs, uint32_t n_pairs,
                                                                 ContactManifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
-                                                                uint32_t *__restrict__ survivors, const uint16_t *__restrict__ axis_cache)
+                                                                uint32_t *__restrict__ survivors, const uint16_t *__restrict__ axis_cache,
+                                                                const double *__restrict__ gjk_axis_cache)
 {
     constexpr uint32_t NC = CLASSES ? 2 : 1;
     __shared__ uint32_t wave_base[NC][kPretestBlock / 64 + 1];
@@ -433,6 +463,12 @@ __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, Po
         if (keep && axis_cache) {
             const uint32_t code = axis_cache[p];
             if (code && cached_face_separates(b, t, frames, pairs, p, code))
+                keep = false; // (the entry stays as it is)
+        }
+        if (keep && gjk_axis_cache) {
+            const double *c = gjk_axis_cache + 3 * (size_t)p;
+            const Vec3 d{c[0], c[1], c[2]};
+            if (dot(d, d) > 0.0 && cached_direction_separates(b, t, frames, pairs, p, d))
                 keep = false; // (the entry stays as it is)
         }
         if (!keep)
@@ -612,13 +648,13 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 
 hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
-                               hipStream_t stream, bool use_axis_cache)
+                               hipStream_t stream, bool use_axis_cache, const double *gjk_axis_cache)
 {
     *count = list.counters + 2u * (list.calls & 1u);
     *next_count = list.counters + 2u * ((list.calls + 1u) & 1u);
     ++list.calls;
     hipLaunchKernelGGL(k_pair_pretest<false>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
-                       pairs, n_pairs, out, *count, list.survivors, use_axis_cache ? list.axis_cache : nullptr);
+                       pairs, n_pairs, out, *count, list.survivors, use_axis_cache ? list.axis_cache : nullptr, gjk_axis_cache);
     return hipGetLastError();
 }
 
@@ -633,7 +669,7 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         uint32_t *count = list->counters + 2u * (list->calls & 1u), *next = list->counters + 2u * ((list->calls + 1u) & 1u);
         ++list->calls;
         hipLaunchKernelGGL(k_pair_pretest<true>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
-                           frames, pairs, n_pairs, out, count, list->survivors, list->axis_cache);
+                           frames, pairs, n_pairs, out, count, list->survivors, list->axis_cache, nullptr);
         for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,

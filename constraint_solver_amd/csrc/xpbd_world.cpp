@@ -158,13 +158,13 @@ struct xpbd_world {
     size_t history_slot_bytes() const { return ((size_t)xpbd::kDynFields * stride * 8 + (size_t)stride * 4 + 255) / 256 * 256; }
     // SAT in two passes (pre-test pass + survivor list, xpbd_pairs.h): chosen per frame from the share of touching
     // pairs in the previous frame, read back at the broadphase's synchronisation point
-    DeviceBuffer sat_counters, sat_survivors, sat_axis_cache;
+    DeviceBuffer sat_counters, sat_survivors, sat_axis_cache, gjk_axis_cache;
     xpbd::SatScratch sat_scratch{nullptr, nullptr, 0, nullptr};
-    bool sat_two_pass = false, gjk_two_pass = false;
+    bool sat_two_pass = false;
     uint32_t sat_schedule = XPBD_SAT_SCHEDULE_AUTO;
     unsigned long long stats_touching_seen = 0, stats_pair_substeps = 0, stats_pair_substeps_seen = 0;
     DeviceBuffer gjk_counters, gjk_pairs_scratch;   // hit list of the two-kernel GJK/EPA narrowphase (xpbd_gjk.h)
-    xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0};
+    xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0, nullptr};
     // frame_set: which of the two frame sets the substep reads (always 0 outside step_contacts)
     xpbd::ContactBuffers contact_buffers(uint32_t frame_set = 0) const
     {
@@ -296,15 +296,14 @@ int build_neighbours(xpbd_world *w, double dt)
         // picks the cheaper schedule from how many of the pairs examined since the last broadphase were touching.
         // SAT: the pre-test pass also answers the pairs whose cached face axis still separates them (SatScratch), so it
         // pays unless nearly every pair touches (box stacks: 99 % touching, one pass 5 % faster; a pile of boxes with
-        // 40 % touching: two passes 35 % faster).  GJK has no such cache: worth it when most pairs fail the sphere test.
+        // 40 % touching: two passes 35 % faster).  (GJK + EPA always runs the pre-test as a pass of its own: see
+        // narrowphase_contacts.)
         const unsigned long long touching = stats_now[0] - w->stats_touching_seen;
         const unsigned long long examined = w->stats_pair_substeps - w->stats_pair_substeps_seen;
         if (w->sat_schedule != XPBD_SAT_SCHEDULE_AUTO)
-            w->sat_two_pass = w->gjk_two_pass = w->sat_schedule == XPBD_SAT_SCHEDULE_TWO_PASS;
-        else if (examined) {
+            w->sat_two_pass = w->sat_schedule == XPBD_SAT_SCHEDULE_TWO_PASS;
+        else if (examined)
             w->sat_two_pass = touching * 5 < examined * 4;
-            w->gjk_two_pass = touching * 4 < examined;
-        }
         if (w->sat_schedule == XPBD_SAT_SCHEDULE_AUTO && w->two_classes)
             w->sat_two_pass = true; // small and large shapes: the two-pass form sorts the pairs by class (xpbd_pairs.h)
         w->stats_touching_seen = stats_now[0];
@@ -322,6 +321,10 @@ int build_neighbours(xpbd_world *w, double dt)
     w->sat_scratch.counters = w->sat_counters.as<uint32_t>();
     w->sat_scratch.survivors = w->sat_survivors.as<uint32_t>();
     w->sat_scratch.axis_cache = w->sat_axis_cache.as<uint16_t>();
+    if (w->narrowphase == XPBD_NARROWPHASE_GJK_EPA) {
+        XPBD_HIP_TRY(w->gjk_axis_cache.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 24));
+        XPBD_HIP_TRY(hipMemsetAsync(w->gjk_axis_cache.ptr, 0, (size_t)(w->n_pairs ? w->n_pairs : 1) * 24, w->stream));
+    }
     XPBD_HIP_TRY(w->cb_nbr.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_nbr_pair.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_pairs.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 8));
@@ -338,8 +341,11 @@ int narrowphase_contacts(xpbd_world *w, const xpbd::BodyArrays &b, const xpbd::C
     if (w->narrowphase == XPBD_NARROWPHASE_GJK_EPA) {
         if (int rc = ensure_gjk_scratch(w, w->n_pairs))
             return rc;
+        // always with the pre-test as a pass of its own: that pass consults the cached separating directions, which are
+        // part of the narrowphase's semantics (og_gjk_epa_cached of the oracle), not a schedule
+        w->gjk_scratch.axis_cache = w->gjk_axis_cache.as<double>();
         XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.rec, c.pairs, w->n_pairs, nullptr, c.manifolds,
-                                                w->gjk_scratch, true, w->gjk_two_pass ? &w->sat_scratch : nullptr, w->stream));
+                                                w->gjk_scratch, true, &w->sat_scratch, w->stream));
     } else {
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
                                                     w->stream));
@@ -568,7 +574,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_pairs, &w->cb_rec, &w->cb_stat_rec, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
-                            &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->cb_rec_b,
+                            &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_rec_b,
                             &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
     if (w->own_stream)

@@ -223,8 +223,11 @@ typedef struct xpbd_gjk_result {
     double   point_b[3];   /* point_a - point_b = depth * normal */
 } xpbd_gjk_result;
 int  xpbd_world_narrowphase_gjk(xpbd_world *w, const uint32_t *pairs, uint32_t n_pairs, xpbd_gjk_result *out);
-/* Narrowphase used by XPBD_MODE_CONTACTS: the SAT (default: up to 8 points per pair) or GJK + EPA (one point
- * per pair, reference body A / incident body B; a degenerate query gives no contact in that substep). */
+/* Narrowphase used by XPBD_MODE_CONTACTS: the SAT (default: up to 8 points per pair) or GJK + EPA (a clipped face
+ * contact where the penetration normal is a face normal of one of the bodies, else one point with reference body A /
+ * incident body B; a degenerate query gives no contact in that substep).  In the pipeline a pair that GJK finds
+ * separated keeps the direction that proved it, and the pair's next query within the same step call tries that
+ * support plane first (a settled pile: most separated pairs stay separated by the same plane). */
 #define XPBD_NARROWPHASE_SAT     0u
 #define XPBD_NARROWPHASE_GJK_EPA 1u
 int  xpbd_world_set_narrowphase(xpbd_world *w, uint32_t narrowphase);
@@ -232,9 +235,10 @@ int  xpbd_world_set_narrowphase(xpbd_world *w, uint32_t narrowphase);
  * vertex distance): the neighbour lists are built once per step call from spheres inflated by a whole frame of
  * travel, so in a given substep most pairs of a loose scene cannot touch, and those are answered "no contact"
  * without running the query.  (xpbd_world_narrowphase / _gjk, the diagnostic entry points, always run it.)
- * The test can run inside the narrowphase kernel (ONE_PASS) or as a pass of its own followed by the SAT / the GJK
- * over the surviving pairs only (TWO_PASS): identical results, different cost -- AUTO picks per step call from the
- * share of touching pairs in the previous one. */
+ * For the SAT the test can run inside the narrowphase kernel (ONE_PASS) or as a pass of its own followed by the SAT
+ * over the surviving pairs only (TWO_PASS; that pass also answers the pairs still separated by the face axis that
+ * separated them last time -- the SAT's own arithmetic for that face): identical results, different cost -- AUTO
+ * picks per step call from the share of touching pairs in the previous one.  GJK + EPA always runs it as a pass. */
 #define XPBD_SAT_SCHEDULE_AUTO     0u
 #define XPBD_SAT_SCHEDULE_ONE_PASS 1u
 #define XPBD_SAT_SCHEDULE_TWO_PASS 2u

@@ -32,6 +32,8 @@ typedef struct {
 } og_result;
 
 void og_gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, og_result *out);
+int  og_direction_separates(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, o_vec3 d);
+void og_gjk_epa_cached(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, o_vec3 *axis, og_result *out);
 
 #ifdef __cplusplus
 }

@@ -389,6 +389,7 @@ struct op_frame {
     uint32_t *off, *nb, *pair_first;
     uint32_t n_pairs;
     op_manifold *manifolds;
+    o_vec3 *gjk_axis; /* per pair: the direction that separated it in its last GJK query (zero = none), see og_gjk_epa_cached */
     o_frame *past, *p1;
     o_vec3 *past_pos;
     o_rigid *next;
@@ -406,12 +407,13 @@ void op_contacts_set_narrowphase(op_frame *f, int narrowphase) { f->narrowphase 
  * with -n, cosine >= OP_FACE_ALIGN, first maximum, A on ties -- that face is the reference face of a clipped face contact
  * exactly as in the SAT.  Any other normal (an edge-edge contact), and a clip that leaves no point below the reference
  * plane, keep the one EPA point with A as the reference body.  The separation is -depth either way.
+ * `axis`: the pair's cached separating direction (og_gjk_epa_cached), kept from substep to substep of a frame.
  */
 #define OP_FACE_ALIGN 0.999
-static void gjk_manifold(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, op_manifold *m)
+static void gjk_manifold(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, o_vec3 *axis, op_manifold *m)
 {
     og_result r;
-    og_gjk_epa(fa, fb, pa, pb, &r);
+    og_gjk_epa_cached(fa, fb, pa, pb, axis, &r);
     memset(m, 0, sizeof *m);
     m->separated = r.status != OG_PENETRATING; /* a degenerate query yields no contact in this substep */
     if (m->separated)
@@ -500,6 +502,7 @@ op_frame *op_contacts_begin(const o_rigid *bodies, const uint32_t *shape_id, uin
     f->pair_first[n] = n_pairs;
     f->n_pairs = n_pairs;
     f->manifolds = (op_manifold *)malloc(sizeof(op_manifold) * (n_pairs ? n_pairs : 1));
+    f->gjk_axis = (o_vec3 *)calloc(n_pairs ? n_pairs : 1, sizeof(o_vec3)); /* a new pair list: nothing cached */
     f->past = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
     f->p1 = (o_frame *)malloc(sizeof(o_frame) * (n ? n : 1));
     f->past_pos = (o_vec3 *)malloc(sizeof(o_vec3) * (n ? n : 1));
@@ -517,6 +520,7 @@ void op_contacts_end(op_frame *f)
     free(f->nb);
     free(f->pair_first);
     free(f->manifolds);
+    free(f->gjk_axis);
     free(f->past);
     free(f->p1);
     free(f->past_pos);
@@ -561,7 +565,7 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
                     memset(&manifolds[q], 0, sizeof manifolds[q]);
                     manifolds[q].separated = 1;
                 } else if (f->narrowphase == OP_NARROWPHASE_GJK_EPA)
-                    gjk_manifold(p1[i], p1[j], pa, pb, &manifolds[q]);
+                    gjk_manifold(p1[i], p1[j], pa, pb, &f->gjk_axis[q], &manifolds[q]);
                 else
                     op_sat(p1[i], p1[j], pa, pb, &manifolds[q]);
                 if (manifolds[q].separated)

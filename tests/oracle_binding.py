@@ -318,3 +318,17 @@ def gjk_epa(fa, fb, pa, pb):
     r = GjkResult()
     L.og_gjk_epa(frame(*fa), frame(*fb), C.byref(pa), C.byref(pb), C.byref(r))
     return r
+
+
+def gjk_epa_cached(fa, fb, pa, pb, axis):
+    """og_gjk_epa_cached: `axis` (numpy [3], zero = none) is consulted first; returns (result, refreshed axis)."""
+    L = load()
+    if not hasattr(L, "_gjk_cached_ready"):
+        L.og_gjk_epa_cached.restype = None
+        L.og_gjk_epa_cached.argtypes = [Frame, Frame, C.POINTER(Polytope), C.POINTER(Polytope), C.POINTER(Vec3), C.POINTER(GjkResult)]
+        L.og_direction_separates.restype = C.c_int
+        L.og_direction_separates.argtypes = [Frame, Frame, C.POINTER(Polytope), C.POINTER(Polytope), Vec3]
+        L._gjk_cached_ready = True
+    r, a = GjkResult(), Vec3(float(axis[0]), float(axis[1]), float(axis[2]))
+    L.og_gjk_epa_cached(frame(*fa), frame(*fb), C.byref(pa), C.byref(pb), C.byref(a), C.byref(r))
+    return r, a.np()

@@ -116,3 +116,35 @@ def test_random_convex_hulls_sat_equals_epa():
             hits += 1
             assert abs(r.depth + max(m.query)) < 1e-9
     assert hits > 100
+
+
+def test_cached_separating_direction():
+    """The pipeline's cache (og_gjk_epa_cached): a separated query leaves the direction that proved it, the next query of
+    the pair tries that direction first.  It may only ever answer 'separated' for pairs that are separated (up to a
+    rounding-sized overlap), a penetrating pair clears it, and following a pair along a path it answers most queries."""
+    rng = np.random.default_rng(21)
+    hits = queries = 0
+    for _ in range(300):
+        pa, pb = POLYS[rng.integers(3)], POLYS[rng.integers(3)]
+        fa = (rng.uniform(-0.3, 0.3, 3), rand_quat(rng))
+        qb, start = rand_quat(rng), rng.uniform(-1.0, 1.0, 3)
+        start *= 1.6 / np.linalg.norm(start)                          # far enough to start separated ...
+        drift, spin = -start / 40 + rng.normal(size=3) * 0.004, rng.normal(size=4) * 0.01
+        axis = np.zeros(3)
+        for step in range(60):                                        # ... then B drifts through A, tumbling slowly
+            q = qb + spin * step
+            fb = (start + drift * step, q / np.linalg.norm(q))
+            plain = ob.gjk_epa(fa, fb, pa, pb)
+            had = axis.any()
+            cached, axis = ob.gjk_epa_cached(fa, fb, pa, pb, axis)
+            queries += 1
+            if cached.gjk_iterations == 0 and cached.status == ob.GJK_SEPARATED and had:
+                hits += 1                                             # answered by the cached direction
+                m = ob.sat(fa, fb, pa, pb)
+                assert m.separated or max(m.query) > -1e-12
+                assert plain.status != ob.GJK_PENETRATING or plain.depth < 1e-12
+            else:                                                     # the full query: exactly the uncached result
+                assert (cached.status, cached.gjk_iterations, cached.epa_iterations) == (plain.status, plain.gjk_iterations, plain.epa_iterations)
+                assert cached.depth == plain.depth
+                assert axis.any() == (plain.status == ob.GJK_SEPARATED)
+    assert hits > 0.3 * queries
