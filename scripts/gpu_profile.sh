@@ -16,6 +16,12 @@ has() { [[ " $PARTS " == *" $1 "* ]]; }
 trace() { # name, extra args
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$name" -- $B "$@" > "$OUT/trace_$name.log" 2>&1
+  # --stats averages over the whole process (pre-roll and warm-up too); for the contact scenes also keep the per-kernel
+  # time inside the TIMED frames
+  local raw; raw=$(find "$OUT/trace_$name" -name '*kernel_trace.csv' | head -1)
+  if [ -n "$raw" ]; then
+    case $name in pinned*) ;; *) python3 scripts/timed_region_kernels.py "$raw" > "$OUT/timed_$name.json" || true ;; esac
+  fi
 }
 pmc() { # name, "extra args", counters...
   local name=$1 extra=$2; shift 2
@@ -30,6 +36,7 @@ if has trace; then
   trace pinned_substep --only pinned --mode substep
   trace stacks --only stacks_262144_sat
   trace mixed_gjk --only mixed_pile_65536_gjk_epa
+  trace stacks_gjk --mode contacts --no-cpu-baseline --scene stacks --bodies 262144 --narrowphase gjk
   trace mixed_sat --only mixed_pile_65536_sat
   trace joints --only boxes_262144_joints_65536
   trace boxes_pile --only boxes_pile_262144_sat
@@ -53,4 +60,5 @@ if has contacts_pmc; then
   pmc write_mixed_sat "--only mixed_pile_65536_sat" WRITE_SIZE
 fi
 python3 scripts/summarize_profile.py "$OUT" > "$OUT/summary.json"
+find "$OUT" -name '*kernel_trace.csv' -delete      # the raw traces (tens of MB each) stay on the box
 cat "$OUT/summary.json"

@@ -98,6 +98,12 @@ def main(out):
         src = newest(os.path.join(d, "**", "*_kernel_stats.csv"))
         if src:
             shutil.copy(src, os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, name)))
+        timed = os.path.join(out, "timed_%s.json" % name)      # scripts/timed_region_kernels.py: the timed frames only
+        if os.path.exists(timed):
+            try:
+                s.setdefault("timed_frames", {})[name] = json.load(open(timed))
+            except ValueError:
+                pass
     valu, wave = pmc(out, "valu", 20).get("k_step<false>", {}), pmc(out, "wave", 20).get("k_step<false>", {})
     if valu:
         s["pmc_k_step_fused_per_launch"] = {**valu, **wave}
