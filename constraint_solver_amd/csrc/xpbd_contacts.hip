@@ -676,25 +676,8 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
     Vec3 dpos{0.0, 0.0, 0.0};
     Quat drot{0.0, 0.0, 0.0, 0.0};
     uint32_t count = 0;
-    // The neighbours in batches of four: their pair indices, then their point counts, are fetched side by side, so a
-    // body pays two dependent round trips per batch instead of two per neighbour (most neighbours of a loose scene
-    // do not touch, and the whole cost of looking at them is that latency).  Processing order stays ascending.
-    const uint32_t k_end = c.nbr_off[i + 1];
-    for (uint32_t k0 = c.nbr_off[i]; k0 < k_end; k0 += 4) {
-      uint32_t pair_of[4], points_of[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u)
-          pair_of[u] = k0 + u < k_end ? c.nbr_pair[k0 + u] : 0u;
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u)
-          points_of[u] = k0 + u < k_end ? c.manifolds[pair_of[u]].n_points : 0u;
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t n_points = u == 0 ? points_of[0] : (u == 1 ? points_of[1] : (u == 2 ? points_of[2] : points_of[3]));
-        if (n_points == 0)
-            continue;
-        const uint32_t k = k0 + u;
-        const ContactManifold *m = c.manifolds + (u == 0 ? pair_of[0] : (u == 1 ? pair_of[1] : (u == 2 ? pair_of[2] : pair_of[3])));
-        const uint32_t j = c.nbr[k];
+    // One neighbour with contact points: its points' terms added in point order.
+    auto neighbour_terms = [&](uint32_t j, const ContactManifold *m, uint32_t n_points) {
         if (j > i) {
             ++touching;
             points += n_points;
@@ -752,7 +735,49 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
                 ++count;
             }
         }
-      }
+    };
+    // Pass 1 -- which of the body's neighbour slots have contact points: bit u of `touch` = slot k_begin + u.  The
+    // neighbours in batches of four: their pair indices, then their point counts, are fetched side by side, so a body
+    // pays two dependent round trips per batch instead of two per neighbour (most neighbours of a loose scene do not
+    // touch, and the whole cost of looking at them is that latency).
+    // Pass 2 -- the lanes of a wave then walk THEIR OWN touching neighbours, round by round (ascending, so every body
+    // still adds its terms in the oracle's order): a wave runs as many rounds as its busiest body has touching
+    // neighbours.  Walking the slots in lockstep instead made it run every slot that any of its 64 bodies had a
+    // contact in -- in a settled pile of boxes (7.8 neighbours a body, 3.2 of them touching) 14 slots with four lanes in
+    // ten idle in each: 17 % lane utilisation (PMC), 19 000 VALU instructions per wave.
+    const uint32_t k_end = c.nbr_off[i + 1];
+    for (uint32_t k_base = c.nbr_off[i]; k_base < k_end; k_base += 64) { // (64 slots per mask: one trip for all but monsters)
+        const uint32_t k_stop = k_end - k_base > 64u ? k_base + 64u : k_end;
+        unsigned long long touch = 0;
+        for (uint32_t k0 = k_base; k0 < k_stop; k0 += 4) {
+            uint32_t pair_of[4], points_of[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                pair_of[u] = k0 + u < k_stop ? c.nbr_pair[k0 + u] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                points_of[u] = k0 + u < k_stop ? c.manifolds[pair_of[u]].n_points : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (points_of[u])
+                    touch |= 1ull << (k0 - k_base + u);
+        }
+        // (the next round's neighbour and pair index are fetched while this round's points are evaluated)
+        uint32_t j_next = 0, pair_next = 0;
+        if (touch) {
+            const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
+            j_next = c.nbr[k], pair_next = c.nbr_pair[k];
+        }
+        while (touch) {
+            const uint32_t j = j_next;
+            const ContactManifold *m = c.manifolds + pair_next;
+            touch &= touch - 1ull;
+            if (touch) {
+                const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
+                j_next = c.nbr[k], pair_next = c.nbr_pair[k];
+            }
+            neighbour_terms(j, m, m->n_points);
+        }
     }
 
     // joints of this body, ascending joint index (same accumulator: the "mixed-constraint" pass)
