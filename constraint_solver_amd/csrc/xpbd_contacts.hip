@@ -749,7 +749,11 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
     for (uint32_t k_base = c.nbr_off[i]; k_base < k_end; k_base += 64) { // (64 slots per mask: one trip for all but monsters)
         const uint32_t k_stop = k_end - k_base > 64u ? k_base + 64u : k_end;
         unsigned long long touch = 0;
-        for (uint32_t k0 = k_base; k0 < k_stop; k0 += 4) {
+        // (a wave whose bodies all have one or two neighbours -- box stacks -- skips pass 1: nothing to filter there)
+        const bool few = __all(k_stop - k_base <= 2u);
+        if (few)
+            touch = k_stop - k_base == 2u ? 3ull : 1ull;
+        for (uint32_t k0 = k_base; !few && k0 < k_stop; k0 += 4) {
             uint32_t pair_of[4], points_of[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
@@ -776,7 +780,9 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &
                 const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
                 j_next = c.nbr[k], pair_next = c.nbr_pair[k];
             }
-            neighbour_terms(j, m, m->n_points);
+            const uint32_t n_points = m->n_points;
+            if (n_points)
+                neighbour_terms(j, m, n_points);
         }
     }
 
