@@ -738,7 +738,7 @@ __device__ __forceinline__ uint32_t hit_list_entry(const uint32_t *prefix, uint3
 // is not finished here: it goes to the overflow list and the wave-per-hit kernel redoes it from its simplex.
 constexpr uint32_t kSubVerts = 16;      // shape vertices per body
 #ifndef XPBD_EPA_SUB_POLY_VERTS
-#define XPBD_EPA_SUB_POLY_VERTS 20      // 4 + 16 expansions (a build with 6 sends most hits through the overflow path: used to test it)
+#define XPBD_EPA_SUB_POLY_VERTS 18      // 4 + 14 expansions, 32 faces (a build with 6 sends most hits through the overflow path: used to test it)
 #endif
 constexpr uint32_t kSubPolyVerts = XPBD_EPA_SUB_POLY_VERTS;
 constexpr uint32_t kSubRows = kSubPolyVerts < 16 ? 16 : kSubPolyVerts; // the clipper needs 16 rows
@@ -1080,9 +1080,17 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         uint32_t *overflow = hits + n_pairs + kHitSegments * 64, *overflow_count = overflow + n_pairs;
         if (hipError_t e = hipMemsetAsync(overflow_count, 0, 4, stream))
             return e;
-        const uint32_t groups = (n_pairs + 3) / 4;
-        hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
-                           manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+        // 8 lanes per hit where no face has more than four vertices (the manifold's clipper runs one polygon vertex per
+        // lane, and a quadrilateral clipped against a quadrilateral has at most eight), 16 otherwise
+        if (t.max_face_verts <= 4) {
+            const uint32_t groups = (n_pairs + 7) / 8;
+            hipLaunchKernelGGL(k_epa_pairs_sub<8>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
+                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+        } else {
+            const uint32_t groups = (n_pairs + 3) / 4;
+            hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
+                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+        }
         hipLaunchKernelGGL(k_epa_pairs, dim3(n_pairs < 256 ? n_pairs : 256), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds,
                            overflow_count, 1u, next, overflow, n_pairs, seeds);
         return hipGetLastError();
