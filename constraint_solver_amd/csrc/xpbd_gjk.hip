@@ -750,7 +750,7 @@ struct EpaSubLds : GjkVertsT<kSubVerts> {
     uint32_t fi[kSubPolyFaces];
     double fn[kSubPolyFaces][3];
     double fd[kSubPolyFaces];
-    uint8_t ve[kSubPolyVerts][kSubPolyVerts + 4];
+    uint32_t ve[kSubRows];        // the directed-edge marks of GjkLds as bit rows: bit b of ve[a] = edge a -> b (18 <= 32 vertices)
     uint8_t he[kSubPolyFaces][2]; // the horizon of the current iteration (see GjkLds)
 };
 
@@ -769,6 +769,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
                                              GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint32_t lane)
 {
     static_assert(kSubPolyFaces <= 64 && L * 4 >= kSubPolyFaces, "face flags live in one 64-bit mask; at most four faces per lane");
+    static_assert(kSubRows <= 32, "the directed-edge marks are 32-bit rows");
     constexpr uint32_t R = (kSubPolyFaces + L - 1) / L; // faces per lane (rounds)
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
@@ -864,7 +865,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         for (uint32_t j = 0; j < R; ++j)
             if (my_vis[j])
                 for (uint32_t e = 0; e < 3; ++e)
-                    s.ve[face_vertex(pk[j], e)][face_vertex(pk[j], e + 1)] = 1;
+                    atomicOr(&s.ve[face_vertex(pk[j], e)], 1u << face_vertex(pk[j], e + 1));
         __syncthreads();
         uint32_t hz[R];
 #pragma unroll
@@ -872,7 +873,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
             hz[j] = 0;
             if (my_vis[j])
                 for (uint32_t e = 0; e < 3; ++e)
-                    if (!s.ve[face_vertex(pk[j], e + 1)][face_vertex(pk[j], e)])
+                    if (!((s.ve[face_vertex(pk[j], e + 1)] >> face_vertex(pk[j], e)) & 1u))
                         hz[j] |= 1u << e;
         }
         __syncthreads();
@@ -881,7 +882,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         for (uint32_t j = 0; j < R; ++j) {
             if (my_vis[j])
                 for (uint32_t e = 0; e < 3; ++e)
-                    s.ve[face_vertex(pk[j], e)][face_vertex(pk[j], e + 1)] = 0;
+                    s.ve[face_vertex(pk[j], e)] = 0; // (every mark of a row belongs to a visible face: all of them go)
 #pragma unroll
             for (uint32_t e = 0; e < 3; ++e)
                 edge_mask[e] |= group_ballot<L>((hz[j] >> e) & 1u) << (L * j);
@@ -970,8 +971,8 @@ k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frame
     __shared__ EpaSubLds s_all[PW];
     EpaSubLds &s = s_all[threadIdx.x / L];
     const uint32_t lane = threadIdx.x % L;
-    for (uint32_t k = lane; k < sizeof(s.ve) / 4; k += L)
-        reinterpret_cast<uint32_t *>(&s.ve[0][0])[k] = 0;
+    for (uint32_t k = lane; k < kSubRows; k += L)
+        s.ve[k] = 0;
     __shared__ uint32_t prefix[kHitSegments + 1];
     const uint32_t n_hits = hit_list_open(prefix, hit_counts, kHitSegments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x * PW + threadIdx.x / L; h < n_hits; h += gridDim.x * PW) {
