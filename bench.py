@@ -600,6 +600,22 @@ def main():
                                   "once and the kernel is f64-VALU bound, not HBM bound" % args.substeps)
                          if mode == capi.MODE_FUSED else "one launch per substep: state round-trips HBM every substep"},
         }
+        if mode == capi.MODE_FUSED and count == 262144 and args.scene == "boxes-drop":
+            # What actually bounds the fused kernel: the f64 issue rate (no FMA under -ffp-contract=off).  PMC counters
+            # cannot be read from inside the run: these come from the newest committed rocprofv3 --pmc pass of this
+            # same configuration (scripts/gpu_profile.sh ... pmc -> profiles/*_summary.json, derived_k_step_fused).
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+                try:
+                    d = json.load(open(f)).get("derived_k_step_fused")
+                except (OSError, ValueError):
+                    d = None
+                if d:
+                    result["roofline"]["valu"] = {"bound": "f64 VALU issue", "pipe_busy": d.get("f64_valu_pipe_busy"),
+                                                  "lane_utilisation": d.get("lane_utilisation"),
+                                                  "insts_per_wave_substep": d.get("valu_insts_per_wave_substep"),
+                                                  "source": os.path.relpath(f, ROOT)}
+                    break
         extras = world_size == 1 and not args.no_extras and not args.only
         if extras:
             # The HBM roof as measured in THIS run: device-to-device copy of 2 GiB (8x the 256 MiB Infinity Cache) by the

@@ -237,6 +237,36 @@ def test_sat_schedules_give_identical_results(kind, n, width):
     assert all(bits_equal(r, want) for r in results)
 
 
+@pytest.mark.parametrize("narrowphase", [capi.NARROWPHASE_SAT, capi.NARROWPHASE_GJK_EPA])
+def test_separating_axis_caches_through_approach_contact_and_release(narrowphase):
+    """The per-pair caches of the pre-test pass (SAT: the separating face axis, exact by construction; GJK: the separating
+    direction, semantics in the oracle) through every transition inside ONE step call: pairs that stay separated by the
+    same axis (hits), pairs that close in and touch (miss -> full query -> contact), pairs that part again (the entry is
+    refreshed), tumbling bodies whose separating axis changes.  30 substeps per call keep one pair list alive long enough."""
+    kind, n = capi.SCENE_MIXED_DROP, 240
+    bodies, sid = pile(kind, n, 77, 3.0, 3.0)
+    rng = np.random.default_rng(5)
+    bodies[:, 22:25] += rng.normal(0.0, 2.0, (n, 3))                # sideways motion: pairs approach and part within a call
+    bodies[:, 25:28] = rng.normal(0.0, 4.0, (n, 3))                 # ... and tumble
+    polys = ob.polytopes_array(POLY_NAMES[kind])
+    none = np.zeros(0, dtype=capi.JOINT_DTYPE)
+    want, want_stats = bodies, ob.ContactStats()
+    for _ in range(10):
+        want = ob.contacts_step_joints(want, sid, polys, none, 2 * DT, 30, 0.02, narrowphase=int(narrowphase), stats=want_stats)
+    for schedule in (capi.SAT_SCHEDULE_TWO_PASS, capi.SAT_SCHEDULE_ONE_PASS):
+        with capi.World(mode=capi.MODE_CONTACTS) as w:
+            w.set_polytopes(capi.scene_polytopes(kind))
+            w.set_narrowphase(narrowphase)
+            w.set_sat_schedule(schedule)
+            w.upload(bodies, sid)
+            for _ in range(10):
+                w.step(2 * DT, 30)
+            stats = w.contact_stats()
+            assert bits_equal(w.download(), want)
+            assert (stats[1], stats[2]) == (want_stats.n_touching, want_stats.n_points)
+    assert want_stats.n_touching > 2000                             # contacts did happen, and came and went
+
+
 def test_contact_pipeline_dense_clump_matches_oracle():
     """150 boxes in one clump: neighbour lists of 149 entries (beyond the 128-entry LDS stage of the neighbour fill),
     11 175 pairs; pair order, manifolds and the Jacobi sums must still be the oracle's."""
