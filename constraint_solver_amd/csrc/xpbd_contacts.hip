@@ -666,7 +666,7 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
 // a wave's dependent chain is the whole cost): lane `sub` evaluates point `sub` of the manifold, and the terms are then
 // added on every lane in point order -- the same values in the same order, so the same bits.
 template <uint32_t G>
-__device__ __forceinline__ BodyDynamic pair_solve_derive_body(const BodyArrays &b, const ContactBuffers &c, uint32_t i, double h,
+__device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffers &c, uint32_t i, double h,
                                                               const PairBody &self, Vec3 self_past_pos, uint32_t sub, uint32_t &touching,
                                                               uint32_t &points)
 {
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
     if (subset_body(subset, b.n, slot, i)) {
         Vec3 past_pos;
         const PairBody self = load_pair_body(c, i, &past_pos);
-        const BodyDynamic d = pair_solve_derive_body<G>(b, c, i, h, self, past_pos, sub, touching, points);
+        const BodyDynamic d = pair_solve_derive_body<G>(c, i, h, self, past_pos, sub, touching, points);
         if (sub == 0) {
             store_dynamic(dyn_out, b.stride, i, d);
             if (subset.export_rows)
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         {
             Vec3 past_pos;
             const PairBody self = load_pair_body(c, i, &past_pos);
-            d = pair_solve_derive_body<G>(b, c, i, h, self, past_pos, sub, touching, points);
+            d = pair_solve_derive_body<G>(c, i, h, self, past_pos, sub, touching, points);
             s = static_of(b, i, self.inv_mass, self.inv_inertia, self.com);
         }
         if (subset.export_rows && sub == 0)

@@ -585,12 +585,11 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
         if (dot(pnt.w, bn) - best_dist < kEpaTolerance || nv == kMaxEpaVerts)
             break;
 
-        // visibility of "my" two faces (lane, lane + 64); the masks are wave-uniform
+        // visibility of "my" two faces (lane, lane + 64)
         const uint32_t f0 = lane, f1 = lane + 64;
         const uint32_t pk[2] = {f0 < nf ? s.fi[f0] : 0u, f1 < nf ? s.fi[f1] : 0u}; // my faces' vertex indices, read once
         const bool vis0 = f0 < nf && dot(ld3(s.fn, f0), pnt.w - ld3(s.vw, face_vertex(pk[0], 0))) > -kEpaCoplanar;
         const bool vis1 = f1 < nf && dot(ld3(s.fn, f1), pnt.w - ld3(s.vw, face_vertex(pk[1], 0))) > -kEpaCoplanar;
-        const unsigned long long mask0 = __ballot(vis0), mask1 = __ballot(vis1);
 
         // horizon test of my faces' edges: a->b is on the horizon iff no other VISIBLE face holds b->a (a face never holds
         // the reverse of its own edge: its three vertices are distinct, or make_face would have failed).  The visible faces
@@ -959,7 +958,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 // points as vertex indices, a face's three vertex indices in one word, and no staged shape tables (they cost 2 KB and
 // one workgroup per CU: A/B on the mixed pile 1.78e8 -> 1.88e8 body-substeps/s without them) -- give 12 workgroups per CU.
 template <uint32_t L>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L == 8 ? 2 : 3, L == 8 ? 2 : 3)))
 k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                       const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
                                                       ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
