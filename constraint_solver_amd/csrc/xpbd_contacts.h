@@ -49,6 +49,7 @@ struct ContactBuffers {
     double *rec;            // [stride][kRecDoubles] BodyRecord of this substep (xpbd_device.hpp): frames before / after
                             //   integrate, pose after the ground contacts, position before integrate
     const double *stat_rec; // [stride][kStatRecDoubles] StatRecord: inverse mass, inverse inertia, centre of mass
+    const uint32_t *stat_index; // NULL: stat_rec is indexed by body; else stat_rec[stat_index[body]] (mass properties shared per shape)
     ContactManifold *manifolds; // [n_pairs]
     unsigned long long *stats; // [2] touching pairs, manifold points (summed over substeps)
     uint32_t *scan_scratch; // block totals of the scans

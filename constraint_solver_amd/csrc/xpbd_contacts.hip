@@ -630,7 +630,7 @@ __device__ __forceinline__ BodyStatic static_of(const BodyArrays &b, uint32_t i,
 __device__ __forceinline__ PairBody load_pair_body(const ContactBuffers &c, uint32_t i, Vec3 *past_pos = nullptr)
 {
     const BodyRecord r = load_record(c.rec, i);         // two cache lines
-    const StatRecord s = load_stat_record(c.stat_rec, i); // one
+    const StatRecord s = load_stat_record(c.stat_rec, c.stat_index ? c.stat_index[i] : i); // one, or a cached table entry
     PairBody p;
     p.pos = r.pos;
     p.rot = r.rot;

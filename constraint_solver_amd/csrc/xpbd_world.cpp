@@ -146,6 +146,13 @@ struct xpbd_world {
     // second set of per-substep records for the fused "end of substep k + start of substep k + 1" kernel (step_contacts)
     DeviceBuffer cb_rec_b;
     bool stat_rec_valid = false; // the StatRecords mirror the SoA static fields of the bodies uploaded last
+    // Mass properties shared per shape: when every body of a shape has bit-identical inverse mass, inverse inertia and
+    // centre of mass (checked on the host at upload -- the usual case: bodies are instances of a few shapes), the contact
+    // kernels read them from a table of n_shapes StatRecords indexed by shape id (cache resident) instead of gathering a
+    // 128-byte record per body and per neighbour.  Same values, so the same bits.
+    bool stat_shared = false;
+    std::vector<double> stat_shape_host; // [n_shapes][kStatRecDoubles]
+    DeviceBuffer cb_stat_shape;
     DeviceBuffer cb_grid_partials, cb_items_unsorted;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
@@ -189,7 +196,8 @@ struct xpbd_world {
         c.nbr_pair = cb_nbr_pair.as<uint32_t>();
         c.pairs = cb_pairs.as<uint32_t>();
         c.rec = (frame_set ? cb_rec_b : cb_rec).as<double>();
-        c.stat_rec = cb_stat_rec.as<double>();
+        c.stat_rec = stat_shared ? cb_stat_shape.as<double>() : cb_stat_rec.as<double>();
+        c.stat_index = stat_shared ? shape_id.as<uint32_t>() : nullptr;
         c.manifolds = cb_manifolds.as<xpbd::ContactManifold>();
         c.stats = cb_stats.as<unsigned long long>();
         c.scan_scratch = cb_scan.as<uint32_t>();
@@ -263,12 +271,22 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_upper_start.reserve((size_t)st * 4));
     XPBD_HIP_TRY(w->cb_rec.reserve((size_t)xpbd::kRecDoubles * st * 8));
     XPBD_HIP_TRY(w->cb_rec_b.reserve((size_t)xpbd::kRecDoubles * st * 8));
-    if (w->cb_stat_rec.bytes < (size_t)xpbd::kStatRecDoubles * st * 8)
-        w->stat_rec_valid = false;
-    XPBD_HIP_TRY(w->cb_stat_rec.reserve((size_t)xpbd::kStatRecDoubles * st * 8));
-    if (!w->stat_rec_valid) {
-        XPBD_HIP_TRY(xpbd::launch_stat_records(w->arrays(), w->cb_stat_rec.as<double>(), w->stream));
-        w->stat_rec_valid = true;
+    if (w->stat_shared) {
+        if (!w->stat_rec_valid) {
+            XPBD_HIP_TRY(w->cb_stat_shape.reserve(w->stat_shape_host.size() * 8));
+            XPBD_HIP_TRY(hipMemcpyAsync(w->cb_stat_shape.ptr, w->stat_shape_host.data(), w->stat_shape_host.size() * 8,
+                                        hipMemcpyHostToDevice, w->stream));
+            XPBD_HIP_TRY(hipStreamSynchronize(w->stream)); // (pageable source)
+            w->stat_rec_valid = true;
+        }
+    } else {
+        if (w->cb_stat_rec.bytes < (size_t)xpbd::kStatRecDoubles * st * 8)
+            w->stat_rec_valid = false;
+        XPBD_HIP_TRY(w->cb_stat_rec.reserve((size_t)xpbd::kStatRecDoubles * st * 8));
+        if (!w->stat_rec_valid) {
+            XPBD_HIP_TRY(xpbd::launch_stat_records(w->arrays(), w->cb_stat_rec.as<double>(), w->stream));
+            w->stat_rec_valid = true;
+        }
     }
     XPBD_HIP_TRY(w->cb_scan.reserve(((size_t)(w->table_size > st ? w->table_size : st) / 1024 + 8) * 4));
     if (!w->cb_stats.ptr) {
@@ -574,7 +592,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_pairs, &w->cb_rec, &w->cb_stat_rec, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
-                            &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_rec_b,
+                            &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_stat_shape, &w->cb_rec_b,
                             &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
     if (w->own_stream)
@@ -834,6 +852,27 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     w->stride = stride;
     w->stat_rec_valid = false;
     w->max_shape_id = max_shape_id;
+    {
+        // do all bodies of a shape share their mass properties bit for bit?  (see stat_shared)
+        const size_t rec = xpbd::kStatRecDoubles;
+        w->stat_shape_host.assign((size_t)w->n_shapes * rec, 0.0);
+        std::vector<uint8_t> seen(w->n_shapes, 0);
+        w->stat_shared = n != 0;
+        for (uint32_t i = 0; i < n && w->stat_shared; ++i) {
+            const uint32_t sid = shape_id ? shape_id[i] : 0u;
+            double v[xpbd::kStatRecDoubles] = {};
+            v[0] = aos[i].inverse_mass;
+            std::memcpy(v + 1, aos[i].inverse_inertia, 9 * sizeof(double));
+            std::memcpy(v + 10, aos[i].center_of_mass, 3 * sizeof(double));
+            double *slot = w->stat_shape_host.data() + (size_t)sid * rec;
+            if (!seen[sid]) {
+                std::memcpy(slot, v, sizeof v);
+                seen[sid] = 1;
+            } else if (std::memcmp(slot, v, sizeof v) != 0) {
+                w->stat_shared = false;
+            }
+        }
+    }
     w->stepped = false;
     w->trace_rows = 0;
     if (n == 0)

@@ -267,6 +267,35 @@ def test_separating_axis_caches_through_approach_contact_and_release(narrowphase
     assert want_stats.n_touching > 2000                             # contacts did happen, and came and went
 
 
+@pytest.mark.parametrize("narrowphase", [capi.NARROWPHASE_SAT, capi.NARROWPHASE_GJK_EPA])
+def test_bodies_of_one_shape_with_different_masses_match_the_oracle(narrowphase):
+    """The contact kernels take the mass properties from a per-shape table when all bodies of a shape share them bit for
+    bit (the generators' scenes do), from per-body records otherwise: a pile whose bodies all have masses of their own --
+    and one where a single body differs -- against the oracle."""
+    kind, n = capi.SCENE_MIXED_DROP, 200
+    bodies, sid = pile(kind, n, 31, 2.5, 5.0)
+    polys = ob.polytopes_array(POLY_NAMES[kind])
+    none = np.zeros(0, dtype=capi.JOINT_DTYPE)
+    rng = np.random.default_rng(8)
+    for variant in ("all", "one"):
+        b = bodies.copy()
+        scale = rng.uniform(0.5, 2.0, n) if variant == "all" else np.where(np.arange(n) == 17, 0.25, 1.0)
+        b[:, 0] *= scale                                            # inverse mass
+        b[:, 1:10] *= scale[:, None]                                # inverse inertia (a heavier body of the same shape)
+        want, want_stats = b, ob.ContactStats()
+        for _ in range(20):
+            want = ob.contacts_step_joints(want, sid, polys, none, DT, 10, 0.02, narrowphase=int(narrowphase), stats=want_stats)
+        with capi.World(mode=capi.MODE_CONTACTS) as w:
+            w.set_polytopes(capi.scene_polytopes(kind))
+            w.set_narrowphase(narrowphase)
+            w.upload(b, sid)
+            for _ in range(20):
+                w.step(DT, 10)
+            stats = w.contact_stats()
+            assert bits_equal(w.download(), want)
+            assert (stats[1], stats[2]) == (want_stats.n_touching, want_stats.n_points) and stats[1] > 200
+
+
 def test_contact_pipeline_dense_clump_matches_oracle():
     """150 boxes in one clump: neighbour lists of 149 entries (beyond the 128-entry LDS stage of the neighbour fill),
     11 175 pairs; pair order, manifolds and the Jacobi sums must still be the oracle's."""
