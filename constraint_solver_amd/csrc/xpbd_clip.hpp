@@ -93,17 +93,36 @@ __device__ __forceinline__ uint64_t group_bits(unsigned long long wave_mask)
     return L == 64 ? wave_mask : (wave_mask >> first) & ((1ull << (L & 63u)) - 1ull);
 }
 
-// One contact point into either result layout.
+// The pieces of a result in either layout (Manifold: the public one; ContactManifold: the pipeline's, xpbd_pairs.h).
+// Point k of a face contact: on the incident body, and its projection onto the reference plane.
 __device__ __forceinline__ void set_point(Manifold &m, uint32_t k, Vec3 inc, Vec3 ref)
 {
     m.p_inc[k][0] = inc.x, m.p_inc[k][1] = inc.y, m.p_inc[k][2] = inc.z;
     m.p_ref[k][0] = ref.x, m.p_ref[k][1] = ref.y, m.p_ref[k][2] = ref.z;
 }
-__device__ __forceinline__ void set_point(ContactManifold &m, uint32_t k, Vec3 inc, Vec3 ref)
+__device__ __forceinline__ void set_point(ContactManifold &m, uint32_t k, Vec3 inc, Vec3)
 {
-    m.point[k][0][0] = inc.x, m.point[k][0][1] = inc.y, m.point[k][0][2] = inc.z;
-    m.point[k][1][0] = ref.x, m.point[k][1][1] = ref.y, m.point[k][1][2] = ref.z;
+    m.point[k][0] = inc.x, m.point[k][1] = inc.y, m.point[k][2] = inc.z; // (the reader projects it: see ContactManifold)
 }
+// The reference plane of a face contact.
+__device__ __forceinline__ void set_plane(Manifold &, const Plane &) {}
+__device__ __forceinline__ void set_plane(ContactManifold &m, const Plane &pl)
+{
+    m.plane[0] = pl.normal.x, m.plane[1] = pl.normal.y, m.plane[2] = pl.normal.z, m.plane[3] = pl.displacement;
+}
+// The single contact of feature 2 (an edge pair; an EPA query without a face normal).
+__device__ __forceinline__ void set_single_contact(Manifold &m, Vec3 inc, Vec3 ref) { set_point(m, 0, inc, ref); }
+__device__ __forceinline__ void set_single_contact(ContactManifold &m, Vec3 inc, Vec3 ref)
+{
+    m.point[0][0] = inc.x, m.point[0][1] = inc.y, m.point[0][2] = inc.z;
+    m.point[1][0] = ref.x, m.point[1][1] = ref.y, m.point[1][2] = ref.z;
+}
+// The header of the public layout; the pipeline keeps n_points and feature in its per-pair code byte instead.
+__device__ __forceinline__ void set_header(Manifold &m, uint32_t n_points, uint32_t feature, uint32_t index_a, uint32_t index_b, double separation)
+{
+    m.n_points = n_points, m.feature = feature, m.index_a = index_a, m.index_b = index_b, m.separation = separation;
+}
+__device__ __forceinline__ void set_header(ContactManifold &, uint32_t, uint32_t, uint32_t, uint32_t, double) {}
 
 // Face contact of one pair by a group of L lanes: reference face `ref_face` of body R (frame fr, shape dr, world-space
 // vertices world_r), incident body I (fi, di, world_i).  Writes the contact points of *m and returns their number;
@@ -211,6 +230,8 @@ __device__ __forceinline__ uint32_t face_contact_group(const PolytopeTables &t, 
         const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
         set_point(*m, at, pt, on_ref);
     }
+    if (lane == 0)
+        set_plane(*m, ref_plane);
     return kept < kMaxManifoldPoints ? kept : kMaxManifoldPoints;
 }
 

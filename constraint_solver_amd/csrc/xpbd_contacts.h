@@ -51,6 +51,7 @@ struct ContactBuffers {
     const double *stat_rec; // [stride][kStatRecDoubles] StatRecord: inverse mass, inverse inertia, centre of mass
     const uint32_t *stat_index; // NULL: stat_rec is indexed by body; else stat_rec[stat_index[body]] (mass properties shared per shape)
     ContactManifold *manifolds; // [n_pairs]
+    uint8_t *pair_codes;    // [n_pairs] n_points | feature << 4 of every pair (xpbd_pairs.h)
     unsigned long long *stats; // [2] touching pairs, manifold points (summed over substeps)
     uint32_t *scan_scratch; // block totals of the scans
     // joints: CSR body -> incident joints (ascending joint index); joint_off is NULL when there are none

@@ -677,7 +677,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
     Quat drot{0.0, 0.0, 0.0, 0.0};
     uint32_t count = 0;
     // One neighbour with contact points: its points' terms added in point order.
-    auto neighbour_terms = [&](uint32_t j, const ContactManifold *m, uint32_t n_points) {
+    auto neighbour_terms = [&](uint32_t j, const ContactManifold *m, uint32_t n_points, uint32_t feature) {
         if (j > i) {
             ++touching;
             points += n_points;
@@ -688,12 +688,23 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
         // `other` with their own point and only 3-vectors are selected by role -- selecting whole bodies by a
         // per-lane condition made the compiler keep four body records live (255 VGPRs + AGPRs, one wave per SIMD).
         const bool self_is_a = i < j;
-        const bool ref_is_a = m->feature != 1u;
+        const bool ref_is_a = feature != 1u;
         const bool self_is_inc = self_is_a != ref_is_a;
+        // a face contact stores its reference plane and the points on the incident body; their partners on the reference
+        // body are the clipper's projections, re-evaluated with its own expression (xpbd_clip.hpp: Plane::project) -- the
+        // same inputs through the same operations, so the same bits.  Feature 2: the single contact's two points.
+        const bool face = feature != 2u;
+        const Plane ref_plane{Vec3{m->plane[0], m->plane[1], m->plane[2]}, m->plane[3]};
         // one contact point: what it adds to dpos and drot
         auto point_term = [&](uint32_t pt, Vec3 &term_pos, Quat &term_rot) {
-            const Vec3 p_inc{m->point[pt][0][0], m->point[pt][0][1], m->point[pt][0][2]};
-            const Vec3 p_ref{m->point[pt][1][0], m->point[pt][1][1], m->point[pt][1][2]};
+            const Vec3 p_inc{m->point[pt][0], m->point[pt][1], m->point[pt][2]};
+            Vec3 p_ref;
+            if (face) {
+                const double depth = distance(ref_plane, p_inc);
+                p_ref = p_inc - depth * ref_plane.normal;
+            } else {
+                p_ref = Vec3{m->point[1][0], m->point[1][1], m->point[1][2]};
+            }
             const Vec3 p_self = self_is_inc ? p_inc : p_ref, p_other = self_is_inc ? p_ref : p_inc;
             const Vec3 correction = p_ref - p_inc;
             const Vec3 moved_self = frame_delta(self.p1, self.past, p_self), moved_other = frame_delta(other.p1, other.past, p_other);
@@ -760,7 +771,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
                 pair_of[u] = k0 + u < k_stop ? c.nbr_pair[k0 + u] : 0u;
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
-                points_of[u] = k0 + u < k_stop ? c.manifolds[pair_of[u]].n_points : 0u;
+                points_of[u] = k0 + u < k_stop ? (uint32_t)c.pair_codes[pair_of[u]] : 0u;
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
                 if (points_of[u])
@@ -773,16 +784,16 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
             j_next = c.nbr[k], pair_next = c.nbr_pair[k];
         }
         while (touch) {
-            const uint32_t j = j_next;
-            const ContactManifold *m = c.manifolds + pair_next;
+            const uint32_t j = j_next, pair_next_now = pair_next;
+            const ContactManifold *m = c.manifolds + pair_next_now;
             touch &= touch - 1ull;
             if (touch) {
                 const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
                 j_next = c.nbr[k], pair_next = c.nbr_pair[k];
             }
-            const uint32_t n_points = m->n_points;
-            if (n_points)
-                neighbour_terms(j, m, n_points);
+            const uint32_t code = c.pair_codes[pair_next_now];
+            if (code)
+                neighbour_terms(j, m, code & ((1u << kPairCodeFeatureShift) - 1u), code >> kPairCodeFeatureShift);
         }
     }
 
@@ -1075,7 +1086,7 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
                                     uint32_t n_pairs, SatScratch *list, hipStream_t stream)
 {
-    return launch_sat_contacts(b, t, c.rec, c.pairs, n_pairs, c.manifolds, list, stream);
+    return launch_sat_contacts(b, t, c.rec, c.pairs, n_pairs, c.manifolds, c.pair_codes, list, stream);
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,

@@ -41,6 +41,7 @@ struct GjkScratch {
     void *pairs_scratch;
     uint32_t calls;
     double *axis_cache;
+    uint8_t *codes; // with `manifolds`: the pipeline's per-pair code bytes (n_points | feature << 4, xpbd_pairs.h)
 };
 size_t gjk_scratch_bytes(uint32_t n_pairs);
 

@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
                                                   uint32_t *__restrict__ next_survivor_count,
                                                   GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds,
                                                   uint32_t *__restrict__ hit_counts, uint32_t *__restrict__ hits, uint32_t segment_capacity,
-                                                  unsigned long long *__restrict__ seeds, double *__restrict__ axis_cache)
+                                                  unsigned long long *__restrict__ seeds, double *__restrict__ axis_cache,
+                                                  uint8_t *__restrict__ codes)
 {
 #ifdef XPBD_GJK_TIMING
     unsigned long long tick_ = clock64();
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
             out[p].epa_iterations = 0;
         }
         if (manifolds && status != 1)
-            manifolds[p].n_points = 0;
+            codes[p] = 0; // "no contact" lives in the pair's code byte only (xpbd_pairs.h)
         if (axis_cache && queried) {
             double *c = axis_cache + 3 * (size_t)p;
             c[0] = separating.x, c[1] = separating.y, c[2] = separating.z;
@@ -458,7 +459,7 @@ constexpr double kFaceAlign = 0.999; // cosine: 2.6 degrees
 template <uint32_t L, class S>
 __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const ShapeDesc &da, const ShapeDesc &db, const Frame &fa,
                                          const Frame &fb, uint32_t best, double best_dist, GjkResult *__restrict__ r,
-                                         ContactManifold *__restrict__ mf, uint32_t lane)
+                                         ContactManifold *__restrict__ mf, uint8_t *__restrict__ code, uint32_t lane)
 {
     constexpr uint32_t P = L < 16 ? L : 16;
     static_assert(sizeof(s.vw) >= P * 3 * sizeof(double) && sizeof(s.fn) >= (P + kMaxFaceVerts) * 3 * sizeof(double),
@@ -512,24 +513,21 @@ __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const Sh
                                          ref ? s.wa : s.wb, s.vw, s.fn, s.fn + P, mf, lane, iface);
     if (lane != 0)
         return;
-    mf->separation = -best_dist;
+    // (the incident / reference face indices and the separation -best_dist exist in the public SAT layout only)
+    (void)iface;
     if (n_out) {
-        mf->n_points = n_out;
-        mf->feature = ref;
-        mf->index_a = ref ? iface : face[0];
-        mf->index_b = ref ? face[1] : iface;
+        *code = (uint8_t)(n_out | (ref << kPairCodeFeatureShift));
     } else {
-        mf->n_points = 1;
-        mf->feature = 2; // reference body A, incident body B
-        mf->index_a = mf->index_b = 0;
-        set_point(*mf, 0, pb, pa); // pb on the incident body B, pa on the reference body A
+        *code = (uint8_t)(1u | (2u << kPairCodeFeatureShift)); // one point, reference body A, incident body B
+        set_single_contact(*mf, pb, pa);                      // pb on the incident body B, pa on the reference body A
     }
 }
 
 // EPA of one penetrating pair by one wave; the polytope starts from the simplex k_gjk_pairs left.
 __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
-                                         GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint32_t lane)
+                                         GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint8_t *__restrict__ codes,
+                                         uint32_t lane)
 {
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
@@ -537,6 +535,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
     const uint32_t na = da.n_verts, nb = db.n_verts;
     GjkResult *r = out ? out + p : nullptr;
     ContactManifold *mf = manifolds ? manifolds + p : nullptr;
+    uint8_t *const code = manifolds ? codes + p : nullptr;
     uint32_t epa_iters = 0;
     auto finish = [&](int32_t st) {
         if (lane == 0) {
@@ -545,7 +544,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
                 r->epa_iterations = epa_iters;
             }
             if (mf && st != 1)
-                mf->n_points = 0;
+                *code = 0;
         }
     };
 
@@ -687,7 +686,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 
     double best_dist;
     const uint32_t best = closest_face(s, nf, lane, &best_dist);
-    epa_emit<64>(s, t, da, db, fa, fb, best, best_dist, r, mf, lane);
+    epa_emit<64>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, lane);
     finish(1);
 }
 
@@ -765,7 +764,8 @@ __device__ __forceinline__ unsigned long long group_ballot(bool flag)
 template <uint32_t L>
 __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                              const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
-                                             GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint32_t lane)
+                                             GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint8_t *__restrict__ codes,
+                                             uint32_t lane)
 {
     static_assert(kSubPolyFaces <= 64 && L * 4 >= kSubPolyFaces, "face flags live in one 64-bit mask; at most four faces per lane");
     static_assert(kSubRows <= 32, "the directed-edge marks are 32-bit rows");
@@ -776,6 +776,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
     const uint32_t na = da.n_verts, nb = db.n_verts;
     GjkResult *r = out ? out + p : nullptr;
     ContactManifold *mf = manifolds ? manifolds + p : nullptr;
+    uint8_t *const code = manifolds ? codes + p : nullptr;
     uint32_t epa_iters = 0;
     auto finish = [&](int32_t st) {
         if (lane == 0) {
@@ -784,7 +785,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
                 r->epa_iterations = epa_iters;
             }
             if (mf && st != 1)
-                mf->n_points = 0;
+                *code = 0;
         }
     };
     // first / lowest face with the smallest plane distance, over the group
@@ -945,7 +946,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 
     double best_dist;
     const uint32_t best = closest(nf, &best_dist);
-    epa_emit<L>(s, t, da, db, fa, fb, best, best_dist, r, mf, lane);
+    epa_emit<L>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, lane);
     finish(1);
     return true;
 }
@@ -964,7 +965,8 @@ k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frame
                                                       ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
                                                       uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
                                                       uint32_t segment_capacity, const unsigned long long *__restrict__ seeds,
-                                                      uint32_t *__restrict__ overflow_count, uint32_t *__restrict__ overflow)
+                                                      uint32_t *__restrict__ overflow_count, uint32_t *__restrict__ overflow,
+                                                      uint8_t *__restrict__ codes)
 {
     constexpr uint32_t PW = 64 / L;
     __shared__ EpaSubLds s_all[PW];
@@ -976,7 +978,7 @@ k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frame
     const uint32_t n_hits = hit_list_open(prefix, hit_counts, kHitSegments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x * PW + threadIdx.x / L; h < n_hits; h += gridDim.x * PW) {
         const uint32_t p = hit_list_entry(prefix, kHitSegments, hits, segment_capacity, h);
-        const bool done = epa_pair_sub<L>(s, b, t, frames, pairs, p, seeds[p], out, manifolds, lane);
+        const bool done = epa_pair_sub<L>(s, b, t, frames, pairs, p, seeds[p], out, manifolds, codes, lane);
         if (!done) {
             // the marks of the interrupted iteration were cleared before the exits; hand the hit over
             if (lane == 0)
@@ -993,7 +995,8 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
                                                   const uint32_t *__restrict__ pairs, GjkResult *__restrict__ out,
                                                   ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
                                                   uint32_t n_segments, uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
-                                                  uint32_t segment_capacity, const unsigned long long *__restrict__ seeds)
+                                                  uint32_t segment_capacity, const unsigned long long *__restrict__ seeds,
+                                                  uint8_t *__restrict__ codes)
 {
     __shared__ GjkLds s;
     for (uint32_t k = threadIdx.x; k < sizeof(s.ve) / 4; k += 64)
@@ -1002,7 +1005,7 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
     const uint32_t n_hits = hit_list_open(prefix, hit_counts, n_segments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x; h < n_hits; h += gridDim.x) {
         const uint32_t p = hit_list_entry(prefix, n_segments, hits, segment_capacity, h);
-        epa_pair(s, b, t, frames, pairs, p, seeds[p], out, manifolds, threadIdx.x);
+        epa_pair(s, b, t, frames, pairs, p, seeds[p], out, manifolds, codes, threadIdx.x);
         __syncthreads(); // the next hit reuses the LDS
     }
 }
@@ -1041,7 +1044,7 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     const uint32_t *survivors = nullptr;
     uint32_t *survivor_count = nullptr, *next_survivor_count = nullptr;
     if (sphere_pretest && list && manifolds) { // two-pass form: the pre-test pass answers the rejected pairs
-        if (hipError_t e = launch_pair_pretest(b, t, frames, pairs, n_pairs, manifolds, *list, &survivor_count, &next_survivor_count, stream,
+        if (hipError_t e = launch_pair_pretest(b, t, frames, pairs, n_pairs, scratch.codes, *list, &survivor_count, &next_survivor_count, stream,
                                                false, scratch.axis_cache))
             return e;
         survivors = list->survivors;
@@ -1051,6 +1054,7 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     // the cache is part of the pipeline's semantics, and the pre-test pass is where it is consulted: without that pass
     // (the diagnostic entry point, or a caller that wants the pre-test inside the kernel) it is neither read nor written
     double *const axis = survivors ? scratch.axis_cache : nullptr;
+    uint8_t *const codes = manifolds ? scratch.codes : nullptr;
     uint32_t segment_capacity = 0;
     auto launch = [&](auto lanes, auto pretest) {
         constexpr uint32_t L = decltype(lanes)::value, V = L == 32 ? kMaxV : 16;
@@ -1059,10 +1063,10 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         segment_capacity = (grid.x + kHitSegments - 1) / kHitSegments * (64 / L); // what the workgroups of one segment can append
         if (staged)
             hipLaunchKernelGGL((k_gjk_pairs<L, V, P, true>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis);
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis, codes);
         else
             hipLaunchKernelGGL((k_gjk_pairs<L, V, P, false>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis);
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis, codes);
     };
     using std::integral_constant;
     // lanes per pair: XPBD_GJK_SMALL_LANES for shapes of at most 16 vertices (the simplex logic is replicated on every
@@ -1085,19 +1089,19 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         if (t.max_face_verts <= 4) {
             const uint32_t groups = (n_pairs + 7) / 8;
             hipLaunchKernelGGL(k_epa_pairs_sub<8>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
-                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow, codes);
         } else {
             const uint32_t groups = (n_pairs + 3) / 4;
             hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
-                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow);
+                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow, codes);
         }
         hipLaunchKernelGGL(k_epa_pairs, dim3(n_pairs < 256 ? n_pairs : 256), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds,
-                           overflow_count, 1u, next, overflow, n_pairs, seeds);
+                           overflow_count, 1u, next, overflow, n_pairs, seeds, codes);
         return hipGetLastError();
     }
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
     hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, kHitSegments, next, hits,
-                       segment_capacity, seeds);
+                       segment_capacity, seeds, codes);
     return hipGetLastError();
 }
 

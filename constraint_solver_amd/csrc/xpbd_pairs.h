@@ -59,18 +59,23 @@ struct Manifold {
 
 // pairs[2*p], pairs[2*p+1] are body indices (A, B); 8, 16, 32 or 64 lanes per pair.  frames: the bodies' BodyRecords
 // (xpbd_device.hpp), of which the narrowphase reads the post-integrate frame (the first 56 bytes: one cache line).
-// The same result as the contact pipeline stores it: points interleaved (incident, reference) so that the usual
-// manifold of <= 4 points is the first 208 bytes, records 512-byte aligned -- the pair solve reads every manifold
-// twice, and with the 408-byte public layout (p_ref block, then p_inc block, unaligned) a 4-point manifold touched
-// four 128-byte lines per read: PMC showed 346 MB fetched per launch against ~210 MB needed.
-struct alignas(512) ContactManifold {
-    uint32_t n_points;
-    uint32_t feature;
-    uint32_t index_a, index_b;
-    double separation;
-    double point[kMaxManifoldPoints][2][3]; // [k][0] = on the incident body, [k][1] = on the reference body
+// The same result as the contact pipeline stores it (the pair solve reads every manifold twice, and on box stacks those
+// reads are half of its traffic), in two places:
+//  * `codes[p]` -- one byte per pair: n_points | feature << 4.  The per-body solve looks at ALL neighbours of a body and most
+//    of them do not touch: it reads the verdicts from this array (a megabyte, cache resident) and opens a manifold only
+//    when there are points in it; "no contact" is written here only.
+//  * ContactManifold -- the points.  A FACE contact stores its reference plane and the points on the incident body only;
+//    the reader projects them onto the plane with the clipper's own expression (Plane::project: p - distance(plane, p) * n),
+//    so it gets the reference points bit for bit.  Plane + four points = 128 bytes: the usual manifold is ONE cache line
+//    (the public layout above: four; round 1's interleaved 512-byte record: two).  The single contact of an edge pair
+//    or of an EPA query without a face normal (feature 2) stores both of its points: point[0] on the incident body B,
+//    point[1] on the reference body A.
+struct alignas(256) ContactManifold {
+    double plane[4];                     // face contact: reference plane (normal, displacement), world space
+    double point[kMaxManifoldPoints][3]; // see above
 };
-static_assert(sizeof(ContactManifold) == 512, "one contact manifold = four cache lines, the first two hold <= 4 points");
+static_assert(sizeof(ContactManifold) == 256, "plane + four points = the first 128-byte line");
+constexpr uint32_t kPairCodeFeatureShift = 4;
 
 // Result of the reference's edge_axes_separation for one pair (xpbd_edge_query in include/xpbd.h has this layout).
 struct EdgeQuery {
@@ -113,10 +118,10 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
 // also answer the pairs whose cached SAT face axis still separates them (only for a SAT consumer: "separated" is then the
 // SAT's own verdict; GJK's is not defined by face axes).  gjk_axis_cache: GjkScratch::axis_cache of a GJK consumer.
 hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
+                               uint32_t n_pairs, uint8_t *codes, SatScratch &list, uint32_t **count, uint32_t **next_count,
                                hipStream_t stream, bool use_axis_cache = false, const double *gjk_axis_cache = nullptr);
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, SatScratch *list,
+                               uint32_t n_pairs, ContactManifold *out, uint8_t *codes, SatScratch *list,
                                hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form
 
 } // namespace xpbd

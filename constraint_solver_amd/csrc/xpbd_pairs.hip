@@ -115,7 +115,7 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 template <uint32_t L, class Lds, class M>
 __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane,
-                                         uint16_t *__restrict__ axis_cache = nullptr)
+                                         uint16_t *__restrict__ axis_cache = nullptr, uint8_t *__restrict__ codes = nullptr)
 {
     constexpr uint32_t H = L / 2;             // lanes per body in the two-sided stages
     constexpr uint32_t P = L < 16 ? L : 16;   // polygon capacity of the clipper: one vertex per lane, at most 16 (the
@@ -128,9 +128,21 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     const ShapeDesc da = t.desc[sa], db = t.desc[sb];
 
     M *m = out + p;
+    // the pair's verdict (lane 0): the header of the public layout, the pipeline's code byte (xpbd_pairs.h)
+    auto answer = [&](uint32_t n_points, uint32_t feature, uint32_t index_a, uint32_t index_b, double separation) {
+        if (codes)
+            codes[p] = (uint8_t)(n_points | (feature << kPairCodeFeatureShift));
+        set_header(*m, n_points, feature, index_a, index_b, separation);
+    };
+    auto no_contact = [&]() {
+        if (codes)
+            codes[p] = 0;
+        else
+            set_header(*m, 0, 0, 0, 0, 0.0);
+    };
     if (da.n_verts == 0 || db.n_verts == 0 || da.n_faces == 0 || db.n_faces == 0) {
         if (lane == 0)
-            m->n_points = 0; // the reference's .unwrap() / index would panic; the extension reports "no contact"
+            no_contact(); // the reference's .unwrap() / index would panic; the extension reports "no contact"
         return;
     }
 
@@ -172,7 +184,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     const uint32_t face_a = half ? fidx_other : fidx, face_b = half ? fidx : fidx_other;
     if (qa >= 0.0 || qb >= 0.0 || face_a == kNone || face_b == kNone) {
         if (lane == 0) {
-            m->n_points = 0;
+            no_contact();
             if (axis_cache) // the face that separates the pair: the pre-test pass tries it first in the next substep
                 axis_cache[p] = (uint16_t)(qa >= 0.0 ? 1u + 2u * face_a : (qb >= 0.0 ? 2u + 2u * face_b : 0u));
         }
@@ -245,7 +257,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
     reduce_max_first(ebest, eq, L);
     if (ebest >= 0.0) {
         if (lane == 0)
-            m->n_points = 0;
+            no_contact();
         return;
     }
 
@@ -305,12 +317,8 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
                 sp = clamp01((bb - c) / a);
             }
             const Vec3 pa = a0 + d1 * sp, pb = b0 + d2 * tp;
-            m->n_points = 1;
-            m->feature = 2;
-            m->index_a = i;
-            m->index_b = j;
-            m->separation = ebest;
-            set_point(*m, 0, pb, pa);
+            answer(1, 2, i, j, ebest);
+            set_single_contact(*m, pb, pa);
         }
         return;
     }
@@ -327,11 +335,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
                                                     s.world[r ^ 1u], m, lane, iface);
     if (lane != 0)
         return;
-    m->n_points = n_out;
-    m->feature = r;
-    m->index_a = r ? iface : face_a;
-    m->index_b = r ? face_b : iface;
-    m->separation = face_best;
+    answer(n_out, r, r ? iface : face_a, r ? face_b : iface, face_best);
 }
 
 // Tight bounding spheres (centroid, largest vertex distance; no velocity term, no pad) of pair p overlap?  The neighbour
@@ -363,7 +367,7 @@ template <uint32_t L, uint32_t V, bool PRETEST, class M>
 __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(BodyArrays b, PolytopeTables t,
                                                                                const double *__restrict__ frames,
                                                                                const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                                               M *__restrict__ out)
+                                                                               M *__restrict__ out, uint8_t *__restrict__ codes)
 {
     using Lds = typename SatLds<L, V>::Record;
     __shared__ Lds s_all[SatLds<L, V>::PW];
@@ -373,10 +377,10 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_pairs(B
         return;
     if (PRETEST && !tight_spheres_overlap(b, t, frames, pairs, p)) {
         if (lane == 0)
-            out[p].n_points = 0;
+            codes[p] = 0; // (PRETEST is the pipeline's form: it always has the code bytes)
         return;
     }
-    sat_pair<L>(s_all[group], b, t, frames, pairs, p, out, lane);
+    sat_pair<L>(s_all[group], b, t, frames, pairs, p, out, lane, nullptr, codes);
 }
 
 // The pre-test as a pass of its own, one LANE per pair: rejected pairs are answered, the others are appended to a
@@ -449,7 +453,7 @@ __device__ __forceinline__ bool cached_face_separates(const BodyArrays &b, const
 template <bool CLASSES>
 __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, PolytopeTables t, const double *__restrict__ frames,
                                                                 const uint32_t *__restrict__ pairs, uint32_t n_pairs,
-                                                                ContactManifold *__restrict__ out, uint32_t *__restrict__ survivor_count,
+                                                                uint8_t *__restrict__ codes, uint32_t *__restrict__ survivor_count,
                                                                 uint32_t *__restrict__ survivors, const uint16_t *__restrict__ axis_cache,
                                                                 const double *__restrict__ gjk_axis_cache)
 {
@@ -472,7 +476,7 @@ __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, Po
                 keep = false; // (the entry stays as it is)
         }
         if (!keep)
-            out[p].n_points = 0;
+            codes[p] = 0;
         else if (CLASSES) {
             const uint32_t ca = t.shape_class[b.shape_id[pairs[2 * (size_t)p]]], cb = t.shape_class[b.shape_id[pairs[2 * (size_t)p + 1]]];
             cls = ca > cb ? ca : cb;
@@ -514,7 +518,8 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
                                                                                    const uint32_t *__restrict__ survivor_count,
                                                                                    uint32_t *__restrict__ next_survivor_counts,
                                                                                    const uint32_t *__restrict__ survivors, uint32_t back_n,
-                                                                                   ContactManifold *__restrict__ out, uint16_t *__restrict__ axis_cache)
+                                                                                   ContactManifold *__restrict__ out, uint16_t *__restrict__ axis_cache,
+                                                                                   uint8_t *__restrict__ codes)
 {
     using Lds = typename SatLds<L, V>::Record;
     __shared__ Lds s_all[SatLds<L, V>::PW];
@@ -525,7 +530,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
         next_survivor_counts[threadIdx.x] = 0;
     if (k >= n)
         return;
-    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane, axis_cache);
+    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane, axis_cache, codes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -633,7 +638,7 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
         for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_pairs<L, V, false, Manifold>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
-                               frames, pairs, n_pairs, out);
+                               frames, pairs, n_pairs, out, nullptr);
         });
     return hipGetLastError();
 }
@@ -647,19 +652,19 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 }
 
 hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, SatScratch &list, uint32_t **count, uint32_t **next_count,
+                               uint32_t n_pairs, uint8_t *codes, SatScratch &list, uint32_t **count, uint32_t **next_count,
                                hipStream_t stream, bool use_axis_cache, const double *gjk_axis_cache)
 {
     *count = list.counters + 2u * (list.calls & 1u);
     *next_count = list.counters + 2u * ((list.calls + 1u) & 1u);
     ++list.calls;
     hipLaunchKernelGGL(k_pair_pretest<false>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
-                       pairs, n_pairs, out, *count, list.survivors, use_axis_cache ? list.axis_cache : nullptr, gjk_axis_cache);
+                       pairs, n_pairs, codes, *count, list.survivors, use_axis_cache ? list.axis_cache : nullptr, gjk_axis_cache);
     return hipGetLastError();
 }
 
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, SatScratch *list, hipStream_t stream)
+                               uint32_t n_pairs, ContactManifold *out, uint8_t *codes, SatScratch *list, hipStream_t stream)
 {
     if (n_pairs == 0)
         return hipSuccess;
@@ -669,16 +674,16 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         uint32_t *count = list->counters + 2u * (list->calls & 1u), *next = list->counters + 2u * ((list->calls + 1u) & 1u);
         ++list->calls;
         hipLaunchKernelGGL(k_pair_pretest<true>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
-                           frames, pairs, n_pairs, out, count, list->survivors, list->axis_cache, nullptr);
+                           frames, pairs, n_pairs, codes, count, list->survivors, list->axis_cache, nullptr);
         for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,
-                               next, list->survivors, 0u, out, list->axis_cache);
+                               next, list->survivors, 0u, out, list->axis_cache, codes);
         });
         for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs,
-                               count + 1, next, list->survivors, n_pairs, out, list->axis_cache);
+                               count + 1, next, list->survivors, n_pairs, out, list->axis_cache, codes);
         });
         return hipGetLastError();
     }
@@ -687,11 +692,11 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
         if (list) { // pre-test pass, then the SAT over the survivors
             uint32_t *count = nullptr, *next = nullptr;
-            (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, out, *list, &count, &next, stream, true);
+            (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, codes, *list, &count, &next, stream, true);
             hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, 0u, out,
-                               list->axis_cache);
+                               list->axis_cache, codes);
         } else {
-            hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out);
+            hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, codes);
         }
     });
     return hipGetLastError();

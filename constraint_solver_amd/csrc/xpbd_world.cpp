@@ -165,13 +165,13 @@ struct xpbd_world {
     size_t history_slot_bytes() const { return ((size_t)xpbd::kDynFields * stride * 8 + (size_t)stride * 4 + 255) / 256 * 256; }
     // SAT in two passes (pre-test pass + survivor list, xpbd_pairs.h): chosen per frame from the share of touching
     // pairs in the previous frame, read back at the broadphase's synchronisation point
-    DeviceBuffer sat_counters, sat_survivors, sat_axis_cache, gjk_axis_cache;
+    DeviceBuffer sat_counters, sat_survivors, sat_axis_cache, gjk_axis_cache, cb_pair_codes;
     xpbd::SatScratch sat_scratch{nullptr, nullptr, 0, nullptr};
     bool sat_two_pass = false;
     uint32_t sat_schedule = XPBD_SAT_SCHEDULE_AUTO;
     unsigned long long stats_touching_seen = 0, stats_pair_substeps = 0, stats_pair_substeps_seen = 0;
     DeviceBuffer gjk_counters, gjk_pairs_scratch;   // hit list of the two-kernel GJK/EPA narrowphase (xpbd_gjk.h)
-    xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0, nullptr};
+    xpbd::GjkScratch gjk_scratch{nullptr, nullptr, 0, nullptr, nullptr};
     // frame_set: which of the two frame sets the substep reads (always 0 outside step_contacts)
     xpbd::ContactBuffers contact_buffers(uint32_t frame_set = 0) const
     {
@@ -199,6 +199,7 @@ struct xpbd_world {
         c.stat_rec = stat_shared ? cb_stat_shape.as<double>() : cb_stat_rec.as<double>();
         c.stat_index = stat_shared ? shape_id.as<uint32_t>() : nullptr;
         c.manifolds = cb_manifolds.as<xpbd::ContactManifold>();
+        c.pair_codes = cb_pair_codes.as<uint8_t>();
         c.stats = cb_stats.as<unsigned long long>();
         c.scan_scratch = cb_scan.as<uint32_t>();
         c.joints = n_joints ? jt_joints.as<xpbd::Joint>() : nullptr;
@@ -347,6 +348,7 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(w->cb_nbr_pair.reserve((size_t)(w->n_entries ? w->n_entries : 1) * 4));
     XPBD_HIP_TRY(w->cb_pairs.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 8));
     XPBD_HIP_TRY(w->cb_manifolds.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * sizeof(xpbd::ContactManifold)));
+    XPBD_HIP_TRY(w->cb_pair_codes.reserve((size_t)(w->n_pairs ? w->n_pairs : 1)));
     c = w->contact_buffers();
     XPBD_HIP_TRY(xpbd::launch_neighbour_fill(b, c, w->stream));
     w->have_neighbours = true;
@@ -362,6 +364,7 @@ int narrowphase_contacts(xpbd_world *w, const xpbd::BodyArrays &b, const xpbd::C
         // always with the pre-test as a pass of its own: that pass consults the cached separating directions, which are
         // part of the narrowphase's semantics (og_gjk_epa_cached of the oracle), not a schedule
         w->gjk_scratch.axis_cache = w->gjk_axis_cache.as<double>();
+        w->gjk_scratch.codes = c.pair_codes;
         XPBD_HIP_TRY(xpbd::launch_gjk_epa_pairs(b, w->tables(), c.rec, c.pairs, w->n_pairs, nullptr, c.manifolds,
                                                 w->gjk_scratch, true, &w->sat_scratch, w->stream));
     } else {
@@ -592,7 +595,7 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->cb_pairs, &w->cb_rec, &w->cb_stat_rec, &w->cb_manifolds,
                             &w->cb_stats, &w->cb_scan, &w->jt_joints, &w->jt_off, &w->jt_list, &w->gjk_counters,
                             &w->gjk_pairs_scratch, &w->cb_slot_sphere, &w->cb_slot_cell, &w->history,
-                            &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_stat_shape, &w->cb_rec_b,
+                            &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_stat_shape, &w->cb_pair_codes, &w->cb_rec_b,
                             &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
     if (w->own_stream)
