@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
     if (survivors) {
         n_pairs = *survivor_count;
-        if (blockIdx.x == 0 && threadIdx.x < 2)
-            next_survivor_count[threadIdx.x] = 0; // the two counters (one per pair class) of the next launch, see SatScratch
+        if (blockIdx.x == 0 && threadIdx.x < kSurvivorCounters)
+            next_survivor_count[threadIdx.x] = 0; // the counters (one per pair class) of the next launch, see SatScratch
     }
     const bool live = slot < n_pairs;
     const uint32_t p = (survivors && live) ? survivors[slot] : slot;

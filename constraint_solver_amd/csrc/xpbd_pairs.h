@@ -76,6 +76,7 @@ struct alignas(256) ContactManifold {
 };
 static_assert(sizeof(ContactManifold) == 256, "plane + four points = the first 128-byte line");
 constexpr uint32_t kPairCodeFeatureShift = 4;
+constexpr uint32_t kSurvivorCounters = 4; // per set: three pair classes + one of padding (SatScratch)
 
 // Result of the reference's edge_axes_separation for one pair (xpbd_edge_query in include/xpbd.h has this layout).
 struct EdgeQuery {
@@ -88,10 +89,12 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 
 // (The pipeline's statistics -- touching pairs, contact points -- are summed by the pair solve, xpbd_contacts.hip.)
 
-// Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two PAIRS of uint32 (one
-// counter per pair class), zero when idle; launch k appends through pair k & 1 and its consumer kernels zero pair
-// (k + 1) & 1 for the next launch (all launches of one world are stream-ordered).  `survivors`: n_pairs uint32; class 0
-// fills it from the front, class 1 from the back.
+// Device scratch of the two-pass form (pre-test pass + SAT over the survivors).  `counters`: two SETS of
+// kSurvivorCounters uint32 (one counter per pair class), zero when idle; launch k appends through set k & 1 and its
+// consumer kernels zero set (k + 1) & 1 for the next launch (all launches of one world are stream-ordered).
+// `survivors`: 2 * n_pairs uint32.  Mixed worlds sort the pairs into three classes by the SMALL / large class of their
+// shapes (small-small, large-small, large-large): class 0 fills the first n_pairs entries from the front, class 1 from
+// the back, class 2 the second n_pairs entries from the front.
 //
 // `axis_cache` (n_pairs uint16, or null): the face axis that separated a pair the last time the SAT looked at it --
 // 0 = none, else 1 + 2 * face + (0: a face of A, 1: of B).  A pair of a settled pile that is separated by a face axis in

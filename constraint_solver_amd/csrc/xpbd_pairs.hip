@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, Po
                                                                 uint32_t *__restrict__ survivors, const uint16_t *__restrict__ axis_cache,
                                                                 const double *__restrict__ gjk_axis_cache)
 {
-    constexpr uint32_t NC = CLASSES ? 2 : 1;
+    constexpr uint32_t NC = CLASSES ? 3 : 1; // small-small, large-small, large-large pairs (SatScratch)
     __shared__ uint32_t wave_base[NC][kPretestBlock / 64 + 1];
     const uint32_t p = blockIdx.x * kPretestBlock + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool keep = false;
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, Po
             codes[p] = 0;
         else if (CLASSES) {
             const uint32_t ca = t.shape_class[b.shape_id[pairs[2 * (size_t)p]]], cb = t.shape_class[b.shape_id[pairs[2 * (size_t)p + 1]]];
-            cls = ca > cb ? ca : cb;
+            cls = ca + cb;
         }
     }
     unsigned long long mask[NC];
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(kPretestBlock) k_pair_pretest(BodyArrays b, Po
     __syncthreads();
     if (keep) {
         const uint32_t at = wave_base[cls][kPretestBlock / 64] + wave_base[cls][wave] + (uint32_t)__popcll(mask[cls] & ((1ull << lane) - 1ull));
-        survivors[cls ? n_pairs - 1u - at : at] = p;
+        survivors[cls == 0 ? at : (cls == 1 ? n_pairs - 1u - at : n_pairs + at)] = p;
     }
 }
 
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
     const uint32_t group = threadIdx.x / L, lane = threadIdx.x % L;
     const uint32_t k = blockIdx.x * SatLds<L, V>::PW + group;
     const uint32_t n = *survivor_count;
-    if (blockIdx.x == 0 && threadIdx.x < 2)
+    if (blockIdx.x == 0 && threadIdx.x < kSurvivorCounters)
         next_survivor_counts[threadIdx.x] = 0;
     if (k >= n)
         return;
@@ -655,8 +655,8 @@ hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, con
                                uint32_t n_pairs, uint8_t *codes, SatScratch &list, uint32_t **count, uint32_t **next_count,
                                hipStream_t stream, bool use_axis_cache, const double *gjk_axis_cache)
 {
-    *count = list.counters + 2u * (list.calls & 1u);
-    *next_count = list.counters + 2u * ((list.calls + 1u) & 1u);
+    *count = list.counters + kSurvivorCounters * (list.calls & 1u);
+    *next_count = list.counters + kSurvivorCounters * ((list.calls + 1u) & 1u);
     ++list.calls;
     hipLaunchKernelGGL(k_pair_pretest<false>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t, frames,
                        pairs, n_pairs, codes, *count, list.survivors, use_axis_cache ? list.axis_cache : nullptr, gjk_axis_cache);
@@ -669,9 +669,12 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
     if (n_pairs == 0)
         return hipSuccess;
     if (list && t.two_classes) {
-        // pre-test pass into one survivor list per pair class, then the small pairs in narrow groups and the others in the
-        // widest shape's: every wave is full of pairs of its own kind
-        uint32_t *count = list->counters + 2u * (list->calls & 1u), *next = list->counters + 2u * ((list->calls + 1u) & 1u);
+        // pre-test pass into one survivor list per pair class, then every class in groups of its own width: small-small
+        // pairs in narrow groups, large-large pairs in the widest shape's, large-small pairs in half of that (an
+        // icosahedron against a cube has 45 edge axes, against another icosahedron 225: sharing waves, the light pair
+        // waits for the heavy one) -- every wave is full of pairs of its own kind
+        uint32_t *count = list->counters + kSurvivorCounters * (list->calls & 1u);
+        uint32_t *next = list->counters + kSurvivorCounters * ((list->calls + 1u) & 1u);
         ++list->calls;
         hipLaunchKernelGGL(k_pair_pretest<true>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
                            frames, pairs, n_pairs, codes, count, list->survivors, list->axis_cache, nullptr);
@@ -680,10 +683,16 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,
                                next, list->survivors, 0u, out, list->axis_cache, codes);
         });
+        if (t.max_verts <= 16)
+            hipLaunchKernelGGL((k_sat_survivors<16, 16>), dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, count + 1, next,
+                               list->survivors, n_pairs, out, list->axis_cache, codes);
+        else
+            hipLaunchKernelGGL((k_sat_survivors<32, kMaxV>), dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, count + 1, next,
+                               list->survivors, n_pairs, out, list->axis_cache, codes);
         for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs,
-                               count + 1, next, list->survivors, n_pairs, out, list->axis_cache, codes);
+                               count + 2, next, list->survivors + n_pairs, 0u, out, list->axis_cache, codes);
         });
         return hipGetLastError();
     }

@@ -329,11 +329,11 @@ int build_neighbours(xpbd_world *w, double dt)
         w->stats_pair_substeps_seen = w->stats_pair_substeps;
     }
     if (!w->sat_counters.ptr) {
-        XPBD_HIP_TRY(w->sat_counters.reserve(16));
-        XPBD_HIP_TRY(hipMemsetAsync(w->sat_counters.ptr, 0, 16, w->stream));
+        XPBD_HIP_TRY(w->sat_counters.reserve(2 * xpbd::kSurvivorCounters * 4));
+        XPBD_HIP_TRY(hipMemsetAsync(w->sat_counters.ptr, 0, 2 * xpbd::kSurvivorCounters * 4, w->stream));
         w->sat_scratch.calls = 0;
     }
-    XPBD_HIP_TRY(w->sat_survivors.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 4));
+    XPBD_HIP_TRY(w->sat_survivors.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 2 * 4)); // 2 * n_pairs entries: SatScratch
     // the pair list is new: nothing is known about which axis separates which pair
     XPBD_HIP_TRY(w->sat_axis_cache.reserve((size_t)(w->n_pairs ? w->n_pairs : 1) * 2));
     XPBD_HIP_TRY(hipMemsetAsync(w->sat_axis_cache.ptr, 0, (size_t)(w->n_pairs ? w->n_pairs : 1) * 2, w->stream));
