@@ -39,6 +39,10 @@ constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS; // 32
 #ifndef XPBD_SAT_SMALL_LANES
 #define XPBD_SAT_SMALL_LANES 16 // shapes of <= 8 vertices and faces otherwise
 #endif
+#ifndef XPBD_SAT_LS_LANES
+#define XPBD_SAT_LS_LANES 16 // a large (<= 16 vertices) against a small shape; A/B on the mixed pile: 8 lanes 2.31e8, 16 lanes 2.44e8, 32 lanes 2.32e8
+                             // (and 64 instead of 32 lanes for large-large pairs: 2.19e8)
+#endif
 #ifndef XPBD_SAT_MID_LANES
 #define XPBD_SAT_MID_LANES 32 // A/B on 65 536 mixed polyhedra: 16 lanes 5.19e8, 32 lanes 5.59e8 body-substeps/s
 #endif
@@ -684,8 +688,8 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
                                next, list->survivors, 0u, out, list->axis_cache, codes);
         });
         if (t.max_verts <= 16)
-            hipLaunchKernelGGL((k_sat_survivors<16, 16>), dim3((n_pairs + 3) / 4), dim3(64), 0, stream, b, t, frames, pairs, count + 1, next,
-                               list->survivors, n_pairs, out, list->axis_cache, codes);
+            hipLaunchKernelGGL((k_sat_survivors<XPBD_SAT_LS_LANES, 16>), dim3((n_pairs + 64 / XPBD_SAT_LS_LANES - 1) / (64 / XPBD_SAT_LS_LANES)), dim3(64), 0,
+                               stream, b, t, frames, pairs, count + 1, next, list->survivors, n_pairs, out, list->axis_cache, codes);
         else
             hipLaunchKernelGGL((k_sat_survivors<32, kMaxV>), dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, count + 1, next,
                                list->survivors, n_pairs, out, list->axis_cache, codes);
