@@ -423,7 +423,7 @@ def main():
     ap.add_argument("--only", default="", help="profiling aid: run ONLY this part ('pinned', or a contacts sub-result name) "
                                                "with no extras and no CPU leg")
     ap.add_argument("--narrowphase", default="sat", choices=["sat", "gjk"],
-                    help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (one point per pair)")
+                    help="contacts mode: SAT (up to 8 points per pair) or GJK + EPA (face manifolds where the normal is a face normal, else one point)")
     ap.add_argument("--sat-schedule", default="auto", choices=["auto", "one-pass", "two-pass"],
                     help="contacts mode, SAT: pre-test inside the SAT kernel, or as a pass of its own (with the cached separating "
                          "face axes) and the SAT over the survivors; auto = the library's choice.  Same results either way")

@@ -46,9 +46,11 @@ struct GjkScratch {
 size_t gjk_scratch_bytes(uint32_t n_pairs);
 
 // Boolean GJK over all pairs (16 or 32 lanes per pair), then EPA over the penetrating ones (one wave per pair).
-// `out` and `manifolds` may each be NULL: manifolds receives the result as a one-point ContactManifold (reference body A,
-// incident body B) for the contact pipeline.  sphere_pretest / list: the pipeline's pre-test inside the
-// GJK kernel (list == NULL) or as a pass of its own with the GJK over the survivors (see launch_sat_contacts).
+// `out` and `manifolds` may each be NULL: manifolds (with scratch.codes) receives the pipeline's form of the result -- a
+// clipped face contact where the penetration normal is a face normal of one of the bodies, else the single EPA contact
+// (reference body A, incident body B).  sphere_pretest / list: the pipeline's pre-test inside the GJK kernel
+// (list == NULL) or as a pass of its own with the GJK over the survivors (see launch_sat_contacts); the contact pipeline
+// always uses the latter, which is also where the cached separating directions are consulted.
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                 uint32_t n_pairs, GjkResult *out, ContactManifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
                                 SatScratch *list, hipStream_t stream);
