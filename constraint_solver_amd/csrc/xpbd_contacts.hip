@@ -665,6 +665,10 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
 // G = lanes per body.  G = 1: the lane walks the points of a manifold one after the other.  G = 8 (small worlds, where
 // a wave's dependent chain is the whole cost): lane `sub` evaluates point `sub` of the manifold, and the terms are then
 // added on every lane in point order -- the same values in the same order, so the same bits.
+#ifndef XPBD_PAIR_SOLVE_ROUND_POINTS
+#define XPBD_PAIR_SOLVE_ROUND_POINTS 2 // points of a manifold per round, see pass 2 below; A/B (boxes pile / mixed pile SAT / GJK+EPA,
+                                       // 1e8 body-substeps/s): 1 point 5.24 / 2.56 / 2.76, 2 points 5.35 / 2.57 / 2.80, 3 points 5.30 / 2.54 / 2.75
+#endif
 template <uint32_t G>
 __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffers &c, uint32_t i, double h,
                                                               const PairBody &self, Vec3 self_past_pos, uint32_t sub, uint32_t &touching,
@@ -677,8 +681,8 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
     Quat drot{0.0, 0.0, 0.0, 0.0};
     uint32_t count = 0;
     // One neighbour with contact points: its points' terms added in point order.
-    auto neighbour_terms = [&](uint32_t j, const ContactManifold *m, uint32_t n_points, uint32_t feature) {
-        if (j > i) {
+    auto neighbour_terms = [&](uint32_t j, const ContactManifold *m, uint32_t n_points, uint32_t feature, uint32_t pt_begin, uint32_t pt_end) {
+        if (j > i && pt_begin == 0) {
             ++touching;
             points += n_points;
         }
@@ -726,7 +730,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
             term_rot = (0.5 * spin) * self.rot;
         };
         if (G == 1) {
-            for (uint32_t pt = 0; pt < n_points; ++pt) {
+            for (uint32_t pt = pt_begin; pt < pt_end; ++pt) {
                 Vec3 term_pos;
                 Quat term_rot;
                 point_term(pt, term_pos, term_rot);
@@ -777,23 +781,35 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
                 if (points_of[u])
                     touch |= 1ull << (k0 - k_base + u);
         }
-        // (the next round's neighbour and pair index are fetched while this round's points are evaluated)
+        // (the next neighbour and its pair index are fetched while the current one's points are evaluated)
         uint32_t j_next = 0, pair_next = 0;
         if (touch) {
             const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
             j_next = c.nbr[k], pair_next = c.nbr_pair[k];
         }
-        while (touch) {
-            const uint32_t j = j_next, pair_next_now = pair_next;
-            const ContactManifold *m = c.manifolds + pair_next_now;
-            touch &= touch - 1ull;
-            if (touch) {
-                const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
-                j_next = c.nbr[k], pair_next = c.nbr_pair[k];
+        // A round takes at most `chunk` points of a manifold; a longer manifold goes on in the lane's next round.  The
+        // rounds of a wave are as long as their longest share, and in a pile the manifolds have 1.4 points on average but
+        // four in the longest: with whole manifolds per round the lanes idled through two thirds of every round (PMC:
+        // 26 % lane utilisation).  Stacks (every manifold four points) take them whole.  G lanes per body: one point per lane.
+        const uint32_t chunk = (G > 1 || few) ? kMaxManifoldPoints : (uint32_t)XPBD_PAIR_SOLVE_ROUND_POINTS;
+        uint32_t j_cur = 0, pair_cur = 0, code_cur = 0, n_cur = 0, pt = 0;
+        while (touch || pt < n_cur) {
+            if (pt == n_cur) { // this lane's next touching neighbour
+                j_cur = j_next, pair_cur = pair_next;
+                touch &= touch - 1ull;
+                if (touch) {
+                    const uint32_t k = k_base + (uint32_t)__ffsll((long long)touch) - 1u;
+                    j_next = c.nbr[k], pair_next = c.nbr_pair[k];
+                }
+                code_cur = c.pair_codes[pair_cur];
+                n_cur = code_cur & ((1u << kPairCodeFeatureShift) - 1u);
+                pt = 0;
             }
-            const uint32_t code = c.pair_codes[pair_next_now];
-            if (code)
-                neighbour_terms(j, m, code & ((1u << kPairCodeFeatureShift) - 1u), code >> kPairCodeFeatureShift);
+            if (n_cur) { // (zero only after the shortcut above: a listed neighbour that does not touch)
+                const uint32_t stop = n_cur - pt > chunk ? pt + chunk : n_cur;
+                neighbour_terms(j_cur, c.manifolds + pair_cur, n_cur, code_cur >> kPairCodeFeatureShift, pt, stop);
+                pt = stop;
+            }
         }
     }
 
