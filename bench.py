@@ -485,6 +485,7 @@ def main():
     # box stacks; configs[2]: 65 536 mixed convex polyhedra on the GJK/EPA path)
     sub_runs = {
         "stacks_262144_sat": dict(scene="stacks", bodies=262144, narrowphase="sat", joints_n=0, pitch=2.0),
+        "stacks_262144_gjk_epa": dict(scene="stacks", bodies=262144, narrowphase="gjk", joints_n=0, pitch=2.0),
         "boxes_pile_262144_sat": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=0, pitch=1.8, layers=4),
         "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4),
         "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4),

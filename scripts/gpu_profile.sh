@@ -36,7 +36,7 @@ if has trace; then
   trace pinned_substep --only pinned --mode substep
   trace stacks --only stacks_262144_sat
   trace mixed_gjk --only mixed_pile_65536_gjk_epa
-  trace stacks_gjk --mode contacts --no-cpu-baseline --scene stacks --bodies 262144 --narrowphase gjk
+  trace stacks_gjk --only stacks_262144_gjk_epa
   trace mixed_sat --only mixed_pile_65536_sat
   trace joints --only boxes_262144_joints_65536
   trace boxes_pile --only boxes_pile_262144_sat
