@@ -662,8 +662,15 @@ def main():
                 big_contacts = len(big.contacts()) / big_n
             ach = big_bytes / big_s / 1e9
             big_tr = json.load(open(tfile)).get("substep_%d" % big_n, {}).get("bytes_per_launch") if os.path.exists(tfile) else None
+            # ... and what the memory system gives this very ACCESS PATTERN (38 doubles in, 13 out per body: 51 concurrent
+            # streams in the world's field-major layout) with no arithmetic at all -- the kernel's real roof -- and what a
+            # tile-major layout of the same bytes would give
+            pattern = capi.selftest_field_streams(big_n, tile_major=False, repeats=10, device=local_rank)
+            pattern_tiles = capi.selftest_field_streams(big_n, tile_major=True, repeats=10, device=local_rank)
             result["roofline_hbm_resident"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                "frac": ach / HBM_PEAK_GBPS, "peak_measured": measured, "frac_of_measured": ach / measured,
+                                               "peak_access_pattern": pattern, "frac_of_access_pattern": ach / pattern,
+                                               "peak_access_pattern_tile_major": pattern_tiles,
                                                "traffic": big_tr, "kernel": "k_step", "launch_us": big_s * 1e6, "bodies": big_n,
                                                "bytes_per_launch": big_bytes, "body_substeps_per_s": big_n / big_s,
                                                "ground_contacts_per_body": big_contacts,

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
     "xpbd_world_set_sat_schedule",
     "xpbd_world_edge_axes_separation",
-    "xpbd_selftest_hbm_copy", "xpbd_world_snapshot_positions", "xpbd_world_max_displacement2",
+    "xpbd_selftest_hbm_copy", "xpbd_selftest_field_streams", "xpbd_world_snapshot_positions", "xpbd_world_max_displacement2",
     "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
     "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
     "xpbd_multi_world_synchronize", "xpbd_multi_world_download", "xpbd_multi_world_halo_stats", "xpbd_multi_world_contact_stats",
@@ -146,6 +146,7 @@ def hip_lib():
         L.xpbd_step_one.argtypes = [C.c_void_p, _f64p, C.c_uint32, C.c_double, C.c_uint32]
         L.xpbd_selftest_div_sqrt.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _f64p, C.c_uint32]
         L.xpbd_selftest_hbm_copy.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, _f64p]
+        L.xpbd_selftest_field_streams.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, _f64p]
         L.xpbd_world_snapshot_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.xpbd_world_max_displacement2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xpbd_comm_unique_id.argtypes = [C.c_char_p]
@@ -553,6 +554,14 @@ def selftest_hbm_copy(nbytes=1 << 31, repeats=10, device=0):
     """GB/s (read + written) of a device-to-device copy by the library's streaming kernel: the measured HBM roof."""
     out = C.c_double(0.0)
     _check(hip_lib().xpbd_selftest_hbm_copy(device, nbytes, repeats, C.byref(out)))
+    return out.value
+
+
+def selftest_field_streams(bodies=2097152, tile_major=False, repeats=10, device=0):
+    """GB/s of the access pattern of one substep of the pinned path alone (38 doubles in, 13 out per body): the roof of
+    XPBD_MODE_PER_SUBSTEP in the world's field-major layout, or in a tile-major one."""
+    out = C.c_double(0.0)
+    _check(hip_lib().xpbd_selftest_field_streams(device, bodies, 1 if tile_major else 0, repeats, C.byref(out)))
     return out.value
 
 

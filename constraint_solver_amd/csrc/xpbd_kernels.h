@@ -79,6 +79,9 @@ hipError_t launch_contacts_emit(const uint32_t *mask, uint32_t n, const uint32_t
 // variant 0 / 1 one 16-byte element per lane (plain / non-temporal), 2 / 3 grid-stride with four loads in flight.
 constexpr uint32_t kCopyVariants = 4;
 hipError_t launch_copy16(const void *src, void *dst, size_t bytes, uint32_t variant, hipStream_t stream);
+// Diagnostics: the per-substep traffic of the pinned path and nothing else -- kDynFields + kStatFields doubles read, kDynFields
+// written per body, in the world's field-major layout (base[f * stride + i]) or tile-major (64 bodies x all fields contiguous).
+hipError_t launch_field_streams(const double *in, double *out, size_t bodies, bool tile_major, hipStream_t stream);
 
 // Diagnostics: q = a / b, r = sqrt(a), element-wise, all device pointers.
 hipError_t launch_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, uint32_t n,

@@ -321,6 +321,39 @@ hipError_t launch_contacts_emit(const uint32_t *mask, uint32_t n, const uint32_t
     return hipGetLastError();
 }
 
+namespace {
+// The memory system alone on one substep's traffic (xpbd_selftest_field_streams): what XPBD_MODE_PER_SUBSTEP can reach at most
+// in this layout -- 38 + 13 concurrent streams of 512 bytes per wave, which HBM serves well below a two-stream copy.
+template <bool TILE_MAJOR>
+__global__ void __launch_bounds__(64) k_field_streams(const double *__restrict__ in, double *__restrict__ out, size_t n)
+{
+    constexpr uint32_t kIn = kDynFields + kStatFields, kOut = kDynFields;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n)
+        return;
+    const double *src = TILE_MAJOR ? in + (i / 64) * kIn * 64 + i % 64 : in + i;
+    double *dst = TILE_MAJOR ? out + (i / 64) * kOut * 64 + i % 64 : out + i;
+    const size_t step = TILE_MAJOR ? 64 : n;
+    double acc = 0.0;
+#pragma unroll
+    for (uint32_t f = 0; f < kIn; ++f)
+        acc += src[f * step];
+#pragma unroll
+    for (uint32_t f = 0; f < kOut; ++f)
+        dst[f * step] = acc + (double)f;
+}
+} // namespace
+
+hipError_t launch_field_streams(const double *in, double *out, size_t bodies, bool tile_major, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((bodies + 63) / 64));
+    if (tile_major)
+        hipLaunchKernelGGL(k_field_streams<true>, grid, dim3(64), 0, stream, in, out, bodies);
+    else
+        hipLaunchKernelGGL(k_field_streams<false>, grid, dim3(64), 0, stream, in, out, bodies);
+    return hipGetLastError();
+}
+
 hipError_t launch_copy16(const void *src, void *dst, size_t bytes, uint32_t variant, hipStream_t stream)
 {
     const size_t n16 = bytes / 16;

@@ -396,6 +396,11 @@ int  xpbd_selftest_div_sqrt(int32_t device, const double *a, const double *b,
  * 256 MiB Infinity Cache) by the library's own streaming kernel, `repeats` launches timed with HIP events.
  * *gbytes_per_s = (bytes read + bytes written) / time, in 1e9 bytes per second. */
 int  xpbd_selftest_hbm_copy(int32_t device, uint64_t bytes, uint32_t repeats, double *gbytes_per_s);
+/* Diagnostics: what the memory system gives the ACCESS PATTERN of one substep of the pinned path -- 38 doubles read and 13
+ * written per body and nothing else -- in the world's field-major layout (tile_major = 0: 51 concurrent streams of 512
+ * bytes per wave) or tile-major (1: 64 bodies x all fields contiguous); best of `repeats` launches.  This, not the
+ * two-stream copy above, is the roof of XPBD_MODE_PER_SUBSTEP on worlds beyond the Infinity Cache. */
+int  xpbd_selftest_field_streams(int32_t device, uint64_t bodies, uint32_t tile_major, uint32_t repeats, double *gbytes_per_s);
 
 #ifdef __cplusplus
 }

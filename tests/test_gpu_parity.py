@@ -295,3 +295,13 @@ def test_full_size_schedules_agree_and_shards_compose(kind, n, frames):
     got_contacts = contacts_f[in_sample].copy()
     got_contacts[:, 0] //= 97
     assert np.array_equal(got_contacts, want_contacts)
+
+
+def test_selftest_field_streams_reports_a_plausible_rate():
+    """The access-pattern roof of the per-substep form (bench.py reports it next to the kernel's rate): runs, and lands
+    between a tenth of the HBM peak and the peak, field-major below tile-major at a size beyond the Infinity Cache."""
+    field = capi.selftest_field_streams(1 << 20, tile_major=False, repeats=5)
+    tile = capi.selftest_field_streams(1 << 20, tile_major=True, repeats=5)
+    assert 800.0 < field < 8000.0 and 800.0 < tile < 8000.0
+    with pytest.raises(capi.XpbdError):
+        capi.selftest_field_streams(3)
