@@ -18,7 +18,7 @@ ORACLE = os.path.join(ROOT, "oracle")
 
 HIP_SOURCES = ["xpbd_kernels.hip", "xpbd_pairs.hip", "xpbd_contacts.hip", "xpbd_gjk.hip", "xpbd_world.cpp", "xpbd_multi.cpp", "xpbd_rccl.cpp"]
 # -ffp-contract=off is a correctness flag: the reference (Rust) never fuses a*b+c.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-ldl"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
 CXX_FLAGS = ["-O2", "-ffp-contract=off", "-std=c++17", "-Wall", "-Wextra"]
 
 
@@ -44,11 +44,24 @@ def _hipcc():
 
 
 def build_hip(force=False):
+    """One object per source (only the stale ones are recompiled, a few at a time), then the link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB, exist_ok=True)
+    obj_dir = os.path.join(LIB, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     out = os.path.join(LIB, "libxpbd_hip.so")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "xpbd.h")]
-    if force or _newer(out, deps):
-        _run([_hipcc()] + HIP_FLAGS + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [os.path.join(ROOT, "include", "xpbd.h")]
+    jobs, objects = [], []
+    for src in HIP_SOURCES:
+        obj = os.path.join(obj_dir, src + ".o")
+        objects.append(obj)
+        if force or _newer(obj, [os.path.join(CSRC, src)] + headers):
+            jobs.append([_hipcc()] + HIP_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(_run, jobs))
+    if jobs or not os.path.exists(out):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objects + ["-ldl"])
     return out
 
 

@@ -46,7 +46,8 @@ ABI_SYMBOLS = [
     "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
     "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
     "xpbd_multi_world_synchronize", "xpbd_multi_world_download", "xpbd_multi_world_halo_stats", "xpbd_multi_world_contact_stats",
-    "xpbd_halo_cell_key", "xpbd_halo_plan", "xpbd_halo_plan_far",
+    "xpbd_halo_cell_key", "xpbd_halo_plan", "xpbd_halo_plan_far", "xpbd_halo_partition", "xpbd_halo_plan_owned",
+    "xpbd_multi_world_download_owned", "xpbd_multi_world_plan_stats", "xpbd_multi_world_owners",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
 
@@ -163,6 +164,9 @@ def hip_lib():
         L.xpbd_multi_world_download.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.xpbd_multi_world_halo_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), _f64p]
         L.xpbd_multi_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.xpbd_multi_world_download_owned.argtypes = [C.c_void_p, _u32p, C.c_void_p, C.c_uint32, _u32p]
+        L.xpbd_multi_world_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.xpbd_multi_world_owners.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.xpbd_halo_cell_key.argtypes = [_f64p, C.c_double]
         L.xpbd_halo_cell_key.restype = C.c_int64
         L.xpbd_halo_plan.argtypes = [C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p,
@@ -450,7 +454,7 @@ class MultiWorld:
         cfg.contact_pad, cfg.halo_margin, cfg.narrowphase = pad, halo_margin, narrowphase
         self._h = C.c_void_p()
         _check(L.xpbd_multi_world_create(C.byref(self._h), C.byref(cfg)))
-        self.n = 0
+        self.n = self.n_global = 0
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -470,13 +474,14 @@ class MultiWorld:
         _check(hip_lib().xpbd_multi_world_set_polytopes(self._h, descs, len(polytopes)))
 
     def upload(self, bodies, shape_id, first_global, n_global, joints=None):
-        """bodies / shape_id: the bodies this process's shards own, global indices [first_global, first_global + len)."""
+        """bodies / shape_id: the slice of the caller's bodies this process hands over, global indices [first_global,
+        first_global + len), in any order: the library decides who owns what."""
         b = np.ascontiguousarray(bodies, dtype=np.float64).reshape(-1, RIGID_DOUBLES)
         sid = None if shape_id is None else np.ascontiguousarray(shape_id, dtype=np.uint32)
         j = np.zeros(0, dtype=JOINT_DTYPE) if joints is None else np.ascontiguousarray(joints, dtype=JOINT_DTYPE)
         _check(hip_lib().xpbd_multi_world_upload(self._h, b.ctypes.data, None if sid is None else _u32(sid), first_global, b.shape[0],
                                                  n_global, j.ctypes.data if j.size else None, j.size))
-        self.n = b.shape[0]
+        self.n, self.n_global = b.shape[0], n_global
 
     def step(self, dt, substeps):
         _check(hip_lib().xpbd_multi_world_step(self._h, dt, substeps))
@@ -490,6 +495,27 @@ class MultiWorld:
     def download(self):
         out = np.empty((self.n, RIGID_DOUBLES), dtype=np.float64)
         _check(hip_lib().xpbd_multi_world_download(self._h, out.ctypes.data, self.n))
+        return out
+
+    def download_owned(self):
+        """(global ids, (k, 38) states) of the bodies this process's shards own at the moment.  Not collective."""
+        n = C.c_uint32(0)
+        cap = max(self.n_global, 1)
+        ids, out = np.empty(cap, dtype=np.uint32), np.empty((cap, RIGID_DOUBLES), dtype=np.float64)
+        _check(hip_lib().xpbd_multi_world_download_owned(self._h, _u32(ids), out.ctypes.data, cap, C.byref(n)))
+        return ids[: n.value].copy(), out[: n.value].copy()
+
+    def plan_stats(self):
+        """dict: plans, frames undone, bodies that changed owner at the last plan, fewest / most bodies owned by a rank, step
+        calls and the host nanoseconds inside them (enqueueing, waiting for the pair counts, waiting for the frame's end)."""
+        out = (C.c_uint64 * 10)()
+        _check(hip_lib().xpbd_multi_world_plan_stats(self._h, out))
+        keys = ("plans", "rollbacks", "migrated", "owned_min", "owned_max", "steps", "ns_enqueue", "ns_wait_broadphase", "ns_wait_frame")
+        return dict(zip(keys, (int(x) for x in out)))
+
+    def owners(self):
+        out = np.empty(self.n_global, dtype=np.uint8)
+        _check(hip_lib().xpbd_multi_world_owners(self._h, out.ctypes.data, self.n_global))
         return out
 
     def halo_stats(self):
@@ -519,6 +545,34 @@ def halo_plan(cell_keys, n_ranks, rank, joints=None):
     ng, nb = C.c_uint32(0), C.c_uint32(0)
     _check(hip_lib().xpbd_halo_plan(keys.ctypes.data_as(C.POINTER(C.c_int64)), len(keys), n_ranks, rank, j.ctypes.data if j.size else None,
                                     j.size, _u32(ghosts), C.byref(ng), _u32(boundary), C.byref(nb), len(keys)))
+    return ghosts[: ng.value].copy(), boundary[: nb.value].copy()
+
+
+def halo_partition(cell_keys, n_ranks):
+    """owner[g] of every body from the grid-cell keys of ALL bodies: host-only, as xpbd_multi_world_upload cuts the shards."""
+    keys = np.ascontiguousarray(cell_keys, dtype=np.int64)
+    owner = np.zeros(len(keys), dtype=np.uint8)
+    L = hip_lib()
+    L.xpbd_halo_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    _check(L.xpbd_halo_partition(keys.ctypes.data, len(keys), n_ranks, owner.ctypes.data))
+    return owner
+
+
+def halo_plan_owned(cell_keys, owner, n_ranks, rank, joints=None, with_far=False):
+    """(ghost ids, boundary ids[, far flags per owned body]) of one rank from the cell keys and owners of ALL bodies."""
+    keys = np.ascontiguousarray(cell_keys, dtype=np.int64)
+    own = np.ascontiguousarray(owner, dtype=np.uint8)
+    j = np.zeros(0, dtype=JOINT_DTYPE) if joints is None else np.ascontiguousarray(joints, dtype=JOINT_DTYPE)
+    ghosts, boundary = np.zeros(len(keys), dtype=np.uint32), np.zeros(len(keys), dtype=np.uint32)
+    far = np.zeros(len(keys), dtype=np.uint8)
+    ng, nb = C.c_uint32(0), C.c_uint32(0)
+    L = hip_lib()
+    L.xpbd_halo_plan_owned.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p,
+                                       _u32p, C.c_void_p, C.c_uint32]
+    _check(L.xpbd_halo_plan_owned(keys.ctypes.data, own.ctypes.data, len(keys), n_ranks, rank, j.ctypes.data if j.size else None, j.size,
+                                  _u32(ghosts), C.byref(ng), _u32(boundary), C.byref(nb), far.ctypes.data if with_far else None, len(keys)))
+    if with_far:
+        return ghosts[: ng.value].copy(), boundary[: nb.value].copy(), far[: int((own == rank).sum())].copy()
     return ghosts[: ng.value].copy(), boundary[: nb.value].copy()
 
 

@@ -36,6 +36,15 @@ namespace xpbd {
 //           substep k + 1 unless `last`)
 // Same arithmetic per body as xpbd_world_step, so the same bits.
 int halo_frame_begin(xpbd_world *w, double dt, double h);
+// ... in two halves, so that a host driving several shards enqueues the broadphase of ALL of them before it waits for any:
+// enqueue = bounding spheres, buckets, neighbour counts, the totals on their way to pinned host memory (no wait);
+// collect = wait for the totals, size the pair buffers, fill the lists, integrate + ground stage of substep 0.
+int halo_frame_begin_enqueue(xpbd_world *w, double dt);
+int halo_frame_begin_collect(xpbd_world *w, double h);
+// The state a frame starts from (13 dynamic fields per body + last contact masks) kept aside on the device / put back:
+// a frame whose halos turn out to have been too thin is undone, re-planned and run again (xpbd_multi.cpp).
+int frame_snapshot_save(xpbd_world *w);
+int frame_snapshot_restore(xpbd_world *w);
 int halo_substep_boundary(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
 int halo_substep_interior(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
 int halo_substep_ghosts(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);

@@ -5,24 +5,36 @@
 // bodies are sharded over the GPUs of one node.  Parity: sharded == single device, bit for bit (tests).
 //
 // One xpbd_multi_world drives the LOCAL shards of a world of n_ranks shards -- all of them (a single process that owns
-// every GPU of the node: what a Rust host would do) or one each (one process per GPU, the ranks of a launcher).  A shard is
-// an ordinary xpbd_world in XPBD_MODE_CONTACTS that holds its OWNED bodies (a contiguous global index range) plus GHOST
-// copies of the remote bodies that can reach an owned body before the next plan, in ascending global id -- so every
-// neighbour list and every floating-point sum has the order of the single-device run.  Per substep:
-//     substep on owned + ghost bodies  ->  export the owned boundary bodies' 13 dynamic doubles  ->  ONE all-gather
-//     (RCCL over xGMI: ncclAllGather, all local shards in one group call)  ->  import into the ghosts.
-// The halo plan (who mirrors whom) is built HERE, in C++, from the shards' own bodies plus three small all-gathers (cell keys,
-// boundary lists, boundary records); no rank ever holds the global scene.  Once per frame the largest distance any owned
-// body has travelled since the plan is reduced over all ranks: beyond halo_margin the step fails with XPBD_E_HALO (a
-// remote contact may have been missed) instead of silently losing contacts, and with XPBD_MULTI_AUTO_REPLAN the halos are
-// re-planned at half the margin.
+// every GPU of the node: what a Rust host would do) or one each (one process per GPU, the ranks of a launcher).
+//
+// Ownership is the LIBRARY's: at every plan the bodies are binned into the cells of a uniform grid (edge = 2 * (largest
+// bounding radius + pad + halo_margin)), the cells are ordered x-major (the spatial-hash cell key) and that sequence is cut
+// into n_ranks runs of near-equal body count -- every rank owns a slab of space, whatever order the caller numbered its
+// bodies in, and a re-plan re-balances the slabs as a pile migrates (bodies change owner then).  A shard is an ordinary
+// xpbd_world in XPBD_MODE_CONTACTS holding its OWNED bodies plus GHOST copies of the remote bodies that can reach an owned
+// body before the next plan, in ascending GLOBAL id (the caller's numbering) -- so every neighbour list and every
+// floating-point sum has the order of the single-device run and the result is that run's, bit for bit.  Per substep:
+//     narrowphase -> boundary bodies (their end-of-substep state straight into the send buffer) -> ONE all-gather (RCCL over
+//     xGMI: ncclAllGather, all local shards in one group call) on a communication stream, overlapping the interior bodies ->
+//     the ghosts take their owners' state from the gathered buffer.
+// The plan (who owns, who mirrors whom) is built HERE, in C++, from the shards' own bodies plus a handful of small
+// all-gathers (cell keys, boundary lists, the records of migrating and boundary bodies); no rank holds the global scene.
+// Every plan-time all-gather carries a status word per rank and so does the frame's last one, so a rank that fails locally
+// (out of memory, say) still takes part in the collectives and EVERY rank returns an error instead of the others hanging.
+//
+// Halo validity is checked at the END of every frame, over all ranks: if a body has used up its travel allowance since the
+// plan, a remote contact may have been missed IN THAT FRAME -- the frame is undone (the state it started from is kept aside
+// on the device), and either re-run after a re-plan (XPBD_MULTI_AUTO_REPLAN) or reported as XPBD_E_HALO with the state of
+// the frame's start in place.  A state with possibly missed contacts never reaches the caller.
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -52,37 +64,31 @@ using xpbd::set_error;
 
 constexpr uint32_t kDyn = 13;    // dynamic doubles per body: position, rotation, velocity, angular velocity
 constexpr uint32_t kRigid = 38;  // sizeof(xpbd_rigid) / 8
-constexpr uint32_t kRecord = 39; // a boundary body's plan-time record: its xpbd_rigid + the shape id
+constexpr uint32_t kRecord = 39; // a body's plan-time record: its xpbd_rigid + the shape id
 constexpr int64_t kCellBias = 1 << 20;
+constexpr int64_t kCellLimit = kCellBias - 4; // |cell| <= this: the +-2 dilations of the planner stay inside the 21-bit fields
 
 struct Range {
     uint32_t first, count;
 };
 
-// Ownership: contiguous index ranges, the first n % w ranks one body longer (constraint_solver_amd/sharding.py).
+// The index slice of the caller's bodies a rank HANDS OVER at upload: contiguous ranges, the first n % w ranks one body
+// longer (constraint_solver_amd/sharding.py).  It says nothing about ownership.
 Range shard_range(uint32_t n, uint32_t rank, uint32_t w)
 {
     const uint32_t base = n / w, extra = n % w;
     return Range{rank * base + std::min(rank, extra), base + (rank < extra ? 1u : 0u)};
 }
 
-uint32_t owner_of(uint32_t g, uint32_t n, uint32_t w)
-{
-    const uint32_t base = n / w, extra = n % w;
-    const uint64_t long_part = (uint64_t)(base + 1) * extra;
-    if (g < long_part)
-        return g / (base + 1);
-    return base ? extra + (uint32_t)((g - long_part) / base) : w - 1;
-}
-
 int64_t clamp_cell(double q)
 {
-    const double lim = (double)(kCellBias - 2);
+    const double lim = (double)kCellLimit;
     if (!(q >= -lim)) // NaN or far negative
-        return -(kCellBias - 2);
-    return q > lim ? kCellBias - 2 : (int64_t)q;
+        return -kCellLimit;
+    return q > lim ? kCellLimit : (int64_t)q;
 }
 
+// x-major: ascending keys are slabs along x, inside a slab rows along y, inside a row columns along z
 int64_t cell_key(int64_t x, int64_t y, int64_t z) { return ((x + kCellBias) << 42) | ((y + kCellBias) << 21) | (z + kCellBias); }
 
 void cell_of_key(int64_t key, int64_t c[3])
@@ -117,13 +123,94 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(ptr); }
 };
 
+// ---- ownership: the x-major sequence of grid cells cut into n_ranks runs of near-equal body count ----------------------------
+// A cut is a (cell key, body id) pair; rank r owns the bodies whose (key, id) lies in [cut[r], cut[r + 1]).  Cuts fall on
+// cell boundaries (whole cells stay together) unless that would leave a rank more than a quarter of its share off balance
+// (many bodies in one cell: a tiny world), in which case the cell is split by body id.
+struct Cut {
+    int64_t key;
+    uint32_t id;
+    bool operator<=(const Cut &o) const { return key < o.key || (key == o.key && id <= o.id); }
+};
+
+void multiselect(int64_t *a, size_t lo, size_t hi, const size_t *pos, size_t n_pos)
+{
+    if (n_pos == 0 || lo >= hi)
+        return;
+    const size_t mid = n_pos / 2;
+    std::nth_element(a + lo, a + pos[mid], a + hi);
+    multiselect(a, lo, pos[mid], pos, mid);
+    multiselect(a, pos[mid] + 1, hi, pos + mid + 1, n_pos - mid - 1);
+}
+
+// cuts[r] for r = 1 .. w - 1 (cuts[0] = the smallest possible pair); a deterministic function of the keys alone
+void partition_cuts(const int64_t *keys, uint32_t n, uint32_t w, std::vector<Cut> &cuts)
+{
+    cuts.assign(w, Cut{INT64_MIN, 0});
+    if (n == 0 || w < 2)
+        return;
+    std::vector<size_t> pos;
+    for (uint32_t r = 1; r < w; ++r) {
+        const size_t t = shard_range(n, r, w).first;
+        if (t < n && (pos.empty() || pos.back() != t))
+            pos.push_back(t);
+    }
+    std::vector<int64_t> a(keys, keys + n);
+    multiselect(a.data(), 0, n, pos.data(), pos.size());
+    const uint32_t share = std::max(1u, n / w);
+    for (uint32_t r = 1; r < w; ++r) {
+        const size_t t = shard_range(n, r, w).first; // bodies the ranks before r should own
+        if (t >= n) {
+            cuts[r] = Cut{INT64_MAX, UINT32_MAX};
+            continue;
+        }
+        const int64_t K = a[t];
+        size_t less = 0, leq = 0;
+        for (uint32_t g = 0; g < n; ++g) {
+            less += keys[g] < K;
+            leq += keys[g] <= K;
+        }
+        const size_t before = t - less, after = leq - t; // bodies of cell K on the wrong side if the cut goes before / after it
+        if (std::min(before, after) * 4 <= share) {
+            cuts[r] = before <= after ? Cut{K, 0} : Cut{K + 1, 0};
+        } else { // split cell K: its `before` lowest ids stay with the ranks before r
+            std::vector<uint32_t> ids;
+            ids.reserve(leq - less);
+            for (uint32_t g = 0; g < n; ++g)
+                if (keys[g] == K)
+                    ids.push_back(g);
+            cuts[r] = Cut{K, ids[before]}; // (ascending already: g runs upwards)
+        }
+    }
+    for (uint32_t r = 1; r < w; ++r) // monotone whatever the snapping did
+        if (!(cuts[r - 1] <= cuts[r]))
+            cuts[r] = cuts[r - 1];
+}
+
+uint32_t owner_of(const std::vector<Cut> &cuts, int64_t key, uint32_t id)
+{
+    // number of cuts <= (key, id), minus one; cuts[0] is the smallest pair
+    uint32_t lo = 0, hi = (uint32_t)cuts.size(); // cuts[lo] <= pair < cuts[hi]
+    const Cut me{key, id};
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (cuts[mid] <= me)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 // Which remote bodies a rank mirrors and which of its own bodies the others mirror; a pure function of the global cell
-// keys and the joints, so every rank computes consistent plans.
+// keys, the owners and the joints, so every rank computes consistent plans.
 struct HaloPlanner {
     uint32_t n = 0, w = 0;
     const int64_t *keys = nullptr;
+    const uint8_t *owner = nullptr; // [n] rank owning body g
 
-    // ghosts: remote bodies in a cell within one cell of a cell this rank owns a body in (ascending);
+    // own:      the rank's bodies (ascending)
+    // ghosts:   remote bodies in a cell within one cell of a cell this rank owns a body in (ascending);
     // boundary: this rank's bodies in a cell within one cell of a cell another rank owns a body in (ascending).
     // A joint between an owned and a remote body puts the remote one among the ghosts and the owned one on the boundary.
     // far (optional, one flag per owned body): no cell within two cells of the body's holds a foreign body.  Such a body
@@ -132,16 +219,19 @@ struct HaloPlanner {
     // two would have to close), the others halo_margin.
     // Cost: one pass over ALL cell keys that only decodes them; everything hashed lies within two cells of this rank's
     // bounding box (the foreign cells next to the slab) or belongs to the rank itself.
-    void plan_rank(uint32_t rank, const xpbd_joint *joints, uint32_t n_joints, std::vector<uint32_t> &ghosts,
+    void plan_rank(uint32_t rank, const xpbd_joint *joints, uint32_t n_joints, std::vector<uint32_t> &own, std::vector<uint32_t> &ghosts,
                    std::vector<uint32_t> &boundary, std::vector<uint8_t> *far = nullptr) const
     {
-        const Range own = shard_range(n, rank, w);
-        const uint32_t own_end = own.first + own.count;
+        own.clear();
+        for (uint32_t g = 0; g < n; ++g)
+            if (owner[g] == rank)
+                own.push_back(g);
+        const uint32_t n_own = (uint32_t)own.size();
         // this rank's unique cells and their bounding box
         std::unordered_map<int64_t, uint8_t> own_cells; // cell -> some other rank owns a body within one cell of it
-        own_cells.reserve((size_t)own.count / 2 + 16);
+        own_cells.reserve((size_t)n_own / 2 + 16);
         int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
-        for (uint32_t g = own.first; g < own_end; ++g)
+        for (uint32_t g : own)
             if (own_cells.emplace(keys[g], 0).second) {
                 int64_t c[3];
                 cell_of_key(keys[g], c);
@@ -153,11 +243,9 @@ struct HaloPlanner {
         // the foreign bodies within two cells of that box: their cells, and (within one cell of an own cell) the ghosts
         std::unordered_set<int64_t> foreign_cells;
         std::vector<uint32_t> candidates; // foreign bodies inside the box grown by one cell: the possible ghosts
-        for (uint32_t g = 0; g < n; ++g) {
-            if (own.count && g == own.first) {
-                g = own_end - 1; // skip the own range
+        for (uint32_t g = 0; g < n && n_own; ++g) {
+            if (owner[g] == rank)
                 continue;
-            }
             int64_t c[3];
             cell_of_key(keys[g], c);
             bool in2 = true, in1 = true;
@@ -165,7 +253,7 @@ struct HaloPlanner {
                 in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
                 in1 = in1 && c[a] >= lo[a] - 1 && c[a] <= hi[a] + 1;
             }
-            if (!in2 || own.count == 0)
+            if (!in2)
                 continue;
             foreign_cells.insert(keys[g]);
             if (in1)
@@ -182,9 +270,9 @@ struct HaloPlanner {
                         seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
             cell.second = seen;
         }
-        std::vector<uint8_t> is_boundary(own.count, 0);
-        for (uint32_t k = 0; k < own.count; ++k)
-            is_boundary[k] = own_cells.find(keys[own.first + k])->second;
+        std::vector<uint8_t> is_boundary(n_own, 0);
+        for (uint32_t k = 0; k < n_own; ++k)
+            is_boundary[k] = own_cells.find(keys[own[k]])->second;
         // a candidate is a ghost iff an own cell lies within one cell of its cell
         std::unordered_map<int64_t, uint8_t> reached; // foreign cell -> within one cell of an own cell (memoised)
         std::vector<uint32_t> ghost_list;
@@ -205,27 +293,27 @@ struct HaloPlanner {
         }
         for (uint32_t j = 0; j < n_joints; ++j) {
             const uint32_t a = joints[j].body_a, b = joints[j].body_b;
-            const bool own_a = a >= own.first && a < own_end, own_b = b >= own.first && b < own_end;
+            const bool own_a = owner[a] == rank, own_b = owner[b] == rank;
             if (own_a && !own_b) {
                 ghost_list.push_back(b);
-                is_boundary[a - own.first] = 1;
+                is_boundary[std::lower_bound(own.begin(), own.end(), a) - own.begin()] = 1;
             } else if (own_b && !own_a) {
                 ghost_list.push_back(a);
-                is_boundary[b - own.first] = 1;
+                is_boundary[std::lower_bound(own.begin(), own.end(), b) - own.begin()] = 1;
             }
         }
         std::sort(ghost_list.begin(), ghost_list.end());
         ghost_list.erase(std::unique(ghost_list.begin(), ghost_list.end()), ghost_list.end());
         ghosts.swap(ghost_list);
         boundary.clear();
-        for (uint32_t k = 0; k < own.count; ++k)
+        for (uint32_t k = 0; k < n_own; ++k)
             if (is_boundary[k])
-                boundary.push_back(own.first + k);
+                boundary.push_back(own[k]);
         if (far) {
             // dilate the nearby foreign cells by two cells; an own body outside that set (and not a boundary body) is far
-            far->assign(own.count, 0);
+            far->assign(n_own, 0);
             const size_t limit = 20000; // beyond that many foreign cells around the slab the dilation is not worth it: nobody is far
-            if (own.count && foreign_cells.size() <= limit) {
+            if (n_own && foreign_cells.size() <= limit) {
                 std::unordered_set<int64_t> near_cells;
                 near_cells.reserve(foreign_cells.size() * 40 + 16);
                 for (int64_t key : foreign_cells) {
@@ -236,8 +324,8 @@ struct HaloPlanner {
                             for (int dz = -2; dz <= 2; ++dz)
                                 near_cells.insert(cell_key(c[0] + dx, c[1] + dy, c[2] + dz));
                 }
-                for (uint32_t k = 0; k < own.count; ++k)
-                    (*far)[k] = !near_cells.count(keys[own.first + k]) && !is_boundary[k];
+                for (uint32_t k = 0; k < n_own; ++k)
+                    (*far)[k] = !near_cells.count(keys[own[k]]) && !is_boundary[k];
             }
         }
     }
@@ -246,22 +334,23 @@ struct HaloPlanner {
 struct Shard {
     int device = 0;
     uint32_t rank = 0;
-    Range own{0, 0};
     xpbd_world *world = nullptr;
     hipStream_t stream = nullptr;      // the shard's world stream: every kernel of the shard
     hipStream_t comm_stream = nullptr; // the per-substep halo all-gather, overlapping the interior bodies' kernels
     ncclComm_t comm = nullptr;
     hipEvent_t ev_send = nullptr, ev_recv = nullptr; // in-process transport
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr; // world stream -> communication stream -> world stream
-    // the owned bodies as last uploaded / re-planned (host): kRigid doubles each, shape ids
-    std::vector<double> owned;
-    std::vector<uint32_t> owned_sid;
+    // The bodies this shard HOLDS (host copies): before the first plan the index slice the caller handed over, after a plan
+    // the bodies it owns.  Ascending global ids, kRigid doubles each, shape ids.  Refreshed from the device by fetch_owned.
+    std::vector<uint32_t> held_ids, held_sid;
+    std::vector<double> held;
     // plan
-    std::vector<uint32_t> local_ids, ghosts, boundary;
+    std::vector<uint32_t> local_ids, ghosts, boundary; // global ids (ascending): owned + ghost bodies; ghosts; mirrored owned bodies
+    std::vector<uint32_t> owned_slots_h;               // local slot of held_ids[i]
     std::vector<uint8_t> far; // per owned body: more than two cells away from every foreign body (larger travel allowance)
-    uint32_t own_slot0 = 0; // local slot of the first owned body (the owned bodies are contiguous in the local order)
     DevBuf boundary_slots, ghost_slots, ghost_rows, owned_slots, skip_flags, disp_scale, send, recv, snapshot, disp, disp_all, stage_send, stage_recv;
-    double *disp_host = nullptr; // pinned, n_ranks doubles
+    double *disp_host = nullptr;   // pinned, n_ranks x {largest squared fraction of an allowance used, status}
+    double *status_host = nullptr; // pinned, this process's status of the frame
 };
 
 } // namespace
@@ -271,18 +360,27 @@ struct xpbd_multi_world {
     double pad = 0.02, margin = 0.5;
     std::vector<Shard> shards;
     const xpbd::RcclApi *rccl = nullptr;
-    bool have_shapes = false, planned = false, violated = false;
+    bool have_shapes = false, planned = false, violated = false, broken = false;
     std::vector<double> shape_radius, shape_centroid; // per shape: max |vertex - centroid|, centroid xyz
     uint32_t n_global = 0, first_global = 0, n_bodies = 0, capacity = 1;
     std::vector<xpbd_joint> joints;
-    uint64_t plans = 0;
+    std::vector<uint8_t> owner;        // [n_global] as of the last plan
+    std::vector<uint32_t> owned_count; // [n_ranks]
+    uint64_t plans = 0, rollbacks = 0, migrated = 0, steps = 0, ns_enqueue = 0, ns_wait_broadphase = 0, ns_wait_frame = 0;
     double cell_edge = 0.0;
     double last_displacement = 0.0; // the largest fraction of its travel allowance any body had used at the last check, times halo_margin
     bool all_local() const { return shards.size() == n_ranks; }
+    bool shortcut() const { return all_local() && !(flags & XPBD_MULTI_PLAN_THROUGH_DEVICE); } // plan-time gathers are memcpys
     uint32_t rows_per_rank() const { return capacity; }
+    Shard *local_shard(uint32_t rank) { return rank >= first_rank && rank < first_rank + shards.size() ? &shards[rank - first_rank] : nullptr; }
 };
 
 namespace {
+
+uint64_t now_ns()
+{
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int bind(const Shard &s)
 {
@@ -295,12 +393,28 @@ int nccl_fail(const xpbd_multi_world *mw, ncclResult_t r, const char *what)
     return set_error(XPBD_E_HIP, "%s failed: %s (RCCL from %s)", what, mw->rccl ? mw->rccl->GetErrorString(r) : "?", mw->rccl ? mw->rccl->path : "?");
 }
 
+// A collective that could not be enqueued leaves the ranks out of step for good: the communicators are aborted (peers
+// blocked in the collective return with an error instead of hanging) and every later call on this world fails.
+int transport_broken(xpbd_multi_world *mw, int rc)
+{
+    const std::string msg = xpbd_last_error();
+    mw->broken = true;
+    if (mw->rccl && mw->rccl->CommAbort)
+        for (Shard &s : mw->shards)
+            if (s.comm) {
+                (void)hipSetDevice(s.device);
+                (void)mw->rccl->CommAbort(s.comm);
+                s.comm = nullptr;
+            }
+    return set_error(rc, "%s -- the communicator is unusable now: destroy this xpbd_multi_world on every rank", msg.c_str());
+}
+
 // One all-gather over all ranks: every local shard contributes `bytes` from its `send` and receives n_ranks x bytes into its
 // `recv` (device pointers, picked per shard by the callbacks), ordered on the shards' streams.
 // `on_comm_stream`: enqueue on the shards' communication streams (the caller orders them against the world streams with
 // events) instead of the world streams.
 template <class Send, class Recv>
-int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv recv_of, bool on_comm_stream = false)
+int all_gather_device_raw(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv recv_of, bool on_comm_stream)
 {
     auto stream_of = [on_comm_stream](Shard &s) { return on_comm_stream ? s.comm_stream : s.stream; };
     if (mw->transport == XPBD_TRANSPORT_RCCL) {
@@ -310,15 +424,19 @@ int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv rec
         ncclResult_t r = mw->rccl->GroupStart();
         if (r != ncclSuccess)
             return nccl_fail(mw, r, "ncclGroupStart");
+        int rc = XPBD_OK;
         for (Shard &s : mw->shards) {
-            MW_TRY(bind(s));
+            if ((rc = bind(s)) != XPBD_OK)
+                break;
             r = mw->rccl->AllGather(send_of(s), recv_of(s), bytes, ncclChar, s.comm, stream_of(s));
             if (r != ncclSuccess) {
-                (void)mw->rccl->GroupEnd();
-                return nccl_fail(mw, r, "ncclAllGather");
+                rc = nccl_fail(mw, r, "ncclAllGather");
+                break;
             }
         }
-        r = mw->rccl->GroupEnd();
+        r = mw->rccl->GroupEnd(); // the group is closed whatever happened inside it
+        if (rc != XPBD_OK)
+            return rc;
         if (r != ncclSuccess)
             return nccl_fail(mw, r, "ncclGroupEnd");
         return XPBD_OK;
@@ -346,32 +464,96 @@ int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv rec
     return XPBD_OK;
 }
 
-// Plan-time all-gather of host data: send[k] = `bytes` of local shard k; out = the n_ranks x bytes everybody ends up with.
-int all_gather_host(xpbd_multi_world *mw, const std::vector<const void *> &send, size_t bytes, std::vector<uint8_t> &out)
+template <class Send, class Recv>
+int all_gather_device(xpbd_multi_world *mw, size_t bytes, Send send_of, Recv recv_of, bool on_comm_stream = false)
 {
+    if (int rc = all_gather_device_raw(mw, bytes, send_of, recv_of, on_comm_stream))
+        return transport_broken(mw, rc);
+    return XPBD_OK;
+}
+
+// The first local error of a collective operation (a plan, a frame).  The operation goes on taking part in its collectives
+// -- with whatever payload -- so that the ranks stay in step, and every collective carries each rank's status: all ranks
+// leave the operation with an error at the same point.
+struct LocalStatus {
+    int rc = XPBD_OK;
+    std::string message;
+    void keep(int r)
+    {
+        if (rc == XPBD_OK && r != XPBD_OK) {
+            rc = r;
+            message = xpbd_last_error();
+        }
+    }
+    bool ok() const { return rc == XPBD_OK; }
+    int report() const { return set_error(rc, "%s", message.c_str()); }
+};
+
+// Plan-time all-gather of host data: send[k] = `bytes` of local shard k; out = the n_ranks x bytes everybody ends up with.
+// Every row is preceded by the sender's status; if any rank reports an error, every rank returns one.
+int all_gather_host(xpbd_multi_world *mw, const std::vector<const void *> &send, size_t bytes, std::vector<uint8_t> &out, LocalStatus &status)
+{
+    const size_t row = bytes + 8;
+    std::vector<uint8_t> all((size_t)mw->n_ranks * row, 0);
+    const int64_t mine = status.rc;
+    if (mw->shortcut()) { // every rank is here: no device round trip needed
+        for (size_t k = 0; k < mw->shards.size(); ++k) {
+            uint8_t *dst = all.data() + (size_t)mw->shards[k].rank * row;
+            std::memcpy(dst, &mine, 8);
+            if (bytes && status.ok())
+                std::memcpy(dst + 8, send[k], bytes);
+        }
+    } else {
+        std::vector<std::vector<uint8_t>> staged(mw->shards.size());
+        int rc = XPBD_OK;
+        auto stage = [&]() -> int {
+            for (size_t k = 0; k < mw->shards.size(); ++k) {
+                Shard &s = mw->shards[k];
+                staged[k].assign(row, 0);
+                std::memcpy(staged[k].data(), &mine, 8);
+                if (bytes && status.ok())
+                    std::memcpy(staged[k].data() + 8, send[k], bytes);
+                MW_TRY(bind(s));
+                MW_HIP_TRY(hipStreamSynchronize(s.stream)); // reserve() may free a block that is still in use
+                MW_HIP_TRY(s.stage_send.reserve(row));
+                MW_HIP_TRY(s.stage_recv.reserve((size_t)mw->n_ranks * row));
+                MW_HIP_TRY(hipMemcpyAsync(s.stage_send.ptr, staged[k].data(), row, hipMemcpyHostToDevice, s.stream));
+            }
+            return XPBD_OK;
+        };
+        if ((rc = stage()) != XPBD_OK) // the staging buffers are the transport's: without them this rank cannot take part
+            return transport_broken(mw, rc);
+        MW_TRY(all_gather_device(mw, row, [](Shard &s) { return s.stage_send.ptr; }, [](Shard &s) { return s.stage_recv.ptr; }));
+        auto collect = [&]() -> int {
+            for (Shard &s : mw->shards) { // every shard takes part in the collective; the content is the same everywhere
+                MW_TRY(bind(s));
+                if (&s == &mw->shards[0])
+                    MW_HIP_TRY(hipMemcpyAsync(all.data(), s.stage_recv.ptr, all.size(), hipMemcpyDeviceToHost, s.stream));
+                MW_HIP_TRY(hipStreamSynchronize(s.stream));
+            }
+            return XPBD_OK;
+        };
+        if ((rc = collect()) != XPBD_OK)
+            return transport_broken(mw, rc);
+    }
     out.assign((size_t)mw->n_ranks * bytes, 0);
-    if (bytes == 0)
-        return XPBD_OK;
-    if (mw->all_local() && !(mw->flags & XPBD_MULTI_PLAN_THROUGH_DEVICE)) { // every rank is here: no device round trip needed
-        for (size_t k = 0; k < mw->shards.size(); ++k)
-            std::memcpy(out.data() + (size_t)mw->shards[k].rank * bytes, send[k], bytes);
-        return XPBD_OK;
+    int64_t peer_rc = 0;
+    uint32_t peer = 0;
+    for (uint32_t r = 0; r < mw->n_ranks; ++r) {
+        int64_t st = 0;
+        std::memcpy(&st, all.data() + (size_t)r * row, 8);
+        if (st != 0 && peer_rc == 0) {
+            peer_rc = st;
+            peer = r;
+        }
+        if (bytes)
+            std::memcpy(out.data() + (size_t)r * bytes, all.data() + (size_t)r * row + 8, bytes);
     }
-    for (size_t k = 0; k < mw->shards.size(); ++k) {
-        Shard &s = mw->shards[k];
-        MW_TRY(bind(s));
-        MW_HIP_TRY(hipStreamSynchronize(s.stream)); // reserve() may free a block that is still in use
-        MW_HIP_TRY(s.stage_send.reserve(bytes));
-        MW_HIP_TRY(s.stage_recv.reserve((size_t)mw->n_ranks * bytes));
-        MW_HIP_TRY(hipMemcpyAsync(s.stage_send.ptr, send[k], bytes, hipMemcpyHostToDevice, s.stream));
-    }
-    MW_TRY(all_gather_device(mw, bytes, [](Shard &s) { return s.stage_send.ptr; }, [](Shard &s) { return s.stage_recv.ptr; }));
-    for (Shard &s : mw->shards) { // every shard takes part in the collective; the content is the same everywhere
-        MW_TRY(bind(s));
-        if (&s == &mw->shards[0])
-            MW_HIP_TRY(hipMemcpyAsync(out.data(), s.stage_recv.ptr, out.size(), hipMemcpyDeviceToHost, s.stream));
-        MW_HIP_TRY(hipStreamSynchronize(s.stream));
-    }
+    if (!status.ok())
+        return status.report();
+    if (peer_rc != 0)
+        return set_error((int)peer_rc, "xpbd_multi_world: rank %u failed with error %d in this collective call (see its xpbd_last_error); "
+                                       "every rank leaves the call with that error", peer, (int)peer_rc);
     return XPBD_OK;
 }
 
@@ -384,155 +566,251 @@ int upload_vector(DevBuf &buf, const std::vector<T> &v, hipStream_t stream)
     return XPBD_OK;
 }
 
-// Builds the halos from the shards' owned bodies (Shard::owned) and uploads every shard's local world.
+struct KeyRow {
+    int64_t key;
+    uint32_t id, sid;
+};
+
+// Builds ownership and halos from the bodies the shards hold (Shard::held*) and uploads every shard's local world.
+// Collective.  Local failures are carried through the collectives (LocalStatus), so all ranks fail together.
 int make_plan(xpbd_multi_world *mw)
 {
     const uint32_t n = mw->n_global, w = mw->n_ranks;
     const size_t n_local = mw->shards.size();
-    // 1. bounding spheres of the owned bodies (centre = position + center_of_mass, radius = r_shape + |centroid - com|:
-    //    conservative whatever the rotation) and the largest radius of the whole world
+    LocalStatus st;
+    std::vector<uint8_t> gathered;
+    std::vector<const void *> send(n_local);
+
+    // 1. bounding spheres of the held bodies (centre = position + center_of_mass, radius = r_shape + |centroid - com|:
+    //    conservative whatever the rotation), the largest radius of the whole world and how many bodies every rank holds
     std::vector<std::vector<double>> centre(n_local);
-    std::vector<double> rmax_local(n_local, 0.0);
+    struct Head {
+        double rmax;
+        uint64_t count;
+    };
+    std::vector<Head> head(n_local, Head{0.0, 0});
     for (size_t k = 0; k < n_local; ++k) {
         const Shard &s = mw->shards[k];
-        centre[k].resize((size_t)3 * s.own.count);
-        for (uint32_t i = 0; i < s.own.count; ++i) {
-            const double *b = &s.owned[(size_t)i * kRigid];
-            const uint32_t sid = s.owned_sid[i];
+        const size_t cnt = s.held_ids.size();
+        head[k].count = cnt;
+        centre[k].resize(3 * cnt);
+        for (size_t i = 0; i < cnt && st.ok(); ++i) {
+            const double *b = &s.held[i * kRigid];
+            const uint32_t sid = s.held_sid[i];
             double off2 = 0.0;
             for (int a = 0; a < 3; ++a) {
-                centre[k][3 * (size_t)i + a] = b[31 + a] + b[28 + a];
+                const double c = b[31 + a] + b[28 + a];
+                if (!std::isfinite(c))
+                    st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u has a non-finite position: it cannot be placed in the grid "
+                                                      "the shards are cut from", s.held_ids[i]));
+                centre[k][3 * i + a] = c;
                 const double d = mw->shape_centroid[3 * (size_t)sid + a] - b[28 + a];
                 off2 += d * d;
             }
             const double r = mw->shape_radius[sid] + std::sqrt(off2);
-            if (r > rmax_local[k])
-                rmax_local[k] = r;
+            if (r > head[k].rmax)
+                head[k].rmax = r;
         }
+        send[k] = &head[k];
     }
-    std::vector<uint8_t> gathered;
-    {
-        std::vector<const void *> send(n_local);
-        for (size_t k = 0; k < n_local; ++k)
-            send[k] = &rmax_local[k];
-        MW_TRY(all_gather_host(mw, send, sizeof(double), gathered));
-    }
+    MW_TRY(all_gather_host(mw, send, sizeof(Head), gathered, st));
     double rmax = 0.0;
-    for (uint32_t r = 0; r < w; ++r)
-        rmax = std::max(rmax, reinterpret_cast<const double *>(gathered.data())[r]);
+    uint64_t max_held = 0, total_held = 0;
+    for (uint32_t r = 0; r < w; ++r) {
+        Head h;
+        std::memcpy(&h, gathered.data() + (size_t)r * sizeof(Head), sizeof h);
+        rmax = std::max(rmax, h.rmax);
+        max_held = std::max(max_held, h.count);
+        total_held += h.count;
+    }
     const double edge = 2.0 * (rmax + mw->pad + mw->margin);
     if (!(edge > 0.0) || !(edge <= 1.0e300))
-        return set_error(XPBD_E_INVALID, "xpbd_multi_world: cell edge %g from radius %g, pad %g, halo_margin %g", edge, rmax, mw->pad, mw->margin);
+        st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: cell edge %g from radius %g, pad %g, halo_margin %g", edge, rmax, mw->pad, mw->margin));
+    if (total_held != n)
+        st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: the ranks hold %llu bodies together, the world has %u", (unsigned long long)total_held, n));
 
-    // 2. grid cell of every body of the world (8 bytes per body, one all-gather)
-    const uint32_t max_count = shard_range(n, 0, w).count;
-    std::vector<std::vector<int64_t>> keys_local(n_local);
-    {
-        std::vector<const void *> send(n_local);
-        for (size_t k = 0; k < n_local; ++k) {
-            const Shard &s = mw->shards[k];
-            keys_local[k].assign(max_count, 0);
-            for (uint32_t i = 0; i < s.own.count; ++i)
-                keys_local[k][i] = cell_key(clamp_cell(std::floor(centre[k][3 * (size_t)i] / edge)), clamp_cell(std::floor(centre[k][3 * (size_t)i + 1] / edge)),
-                                            clamp_cell(std::floor(centre[k][3 * (size_t)i + 2] / edge)));
-            send[k] = keys_local[k].data();
+    // 2. grid cell of every body of the world (16 bytes per body, one all-gather): key, global id, and who holds it
+    std::vector<std::vector<KeyRow>> key_rows(n_local);
+    for (size_t k = 0; k < n_local; ++k) {
+        const Shard &s = mw->shards[k];
+        key_rows[k].assign(max_held, KeyRow{0, UINT32_MAX, 0});
+        for (size_t i = 0; i < s.held_ids.size() && st.ok(); ++i)
+            key_rows[k][i] = KeyRow{cell_key(clamp_cell(std::floor(centre[k][3 * i] / edge)), clamp_cell(std::floor(centre[k][3 * i + 1] / edge)),
+                                             clamp_cell(std::floor(centre[k][3 * i + 2] / edge))),
+                                    s.held_ids[i], s.held_sid[i]};
+        send[k] = key_rows[k].data();
+    }
+    MW_TRY(all_gather_host(mw, send, (size_t)max_held * sizeof(KeyRow), gathered, st));
+    std::vector<int64_t> keys(n, 0);
+    std::vector<uint8_t> holder(n, 0xFF);
+    for (uint32_t r = 0; r < w && st.ok(); ++r) {
+        const KeyRow *rows = reinterpret_cast<const KeyRow *>(gathered.data() + (size_t)r * max_held * sizeof(KeyRow));
+        for (uint64_t i = 0; i < max_held; ++i) {
+            if (rows[i].id == UINT32_MAX)
+                break;
+            if (rows[i].id >= n || holder[rows[i].id] != 0xFF) {
+                st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u is held twice or out of range (rank %u)", rows[i].id, r));
+                break;
+            }
+            keys[rows[i].id] = rows[i].key;
+            holder[rows[i].id] = (uint8_t)r;
         }
-        MW_TRY(all_gather_host(mw, send, (size_t)max_count * 8, gathered));
-    }
-    std::vector<int64_t> keys(n);
-    for (uint32_t r = 0; r < w; ++r) {
-        const Range rr = shard_range(n, r, w);
-        std::memcpy(keys.data() + rr.first, gathered.data() + (size_t)r * max_count * 8, (size_t)rr.count * 8);
     }
 
-    // 3. who mirrors whom
-    HaloPlanner planner;
-    planner.n = n, planner.w = w, planner.keys = keys.data();
-    for (Shard &s : mw->shards)
-        planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), s.ghosts, s.boundary, &s.far);
+    // 3. ownership: the x-major cell sequence cut into runs of near-equal body count; then who mirrors whom
+    std::vector<uint8_t> owner(n, 0);
+    std::vector<uint32_t> owned_count(w, 0);
+    std::vector<std::vector<uint32_t>> own(n_local), exports(n_local);
+    uint64_t migrated = 0;
+    if (st.ok()) {
+        std::vector<Cut> cuts;
+        partition_cuts(keys.data(), n, w, cuts);
+        for (uint32_t g = 0; g < n; ++g) {
+            owner[g] = (uint8_t)owner_of(cuts, keys[g], g);
+            ++owned_count[owner[g]];
+            migrated += owner[g] != holder[g];
+        }
+        HaloPlanner planner;
+        planner.n = n, planner.w = w, planner.keys = keys.data(), planner.owner = owner.data();
+        for (size_t k = 0; k < n_local; ++k) {
+            Shard &s = mw->shards[k];
+            planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), own[k], s.ghosts, s.boundary, &s.far);
+            // what this shard holds and somebody else needs: bodies that change owner, and its (remaining) bodies that others mirror
+            for (uint32_t g : s.held_ids)
+                if (owner[g] != s.rank || std::binary_search(s.boundary.begin(), s.boundary.end(), g))
+                    exports[k].push_back(g);
+        }
+    }
     mw->cell_edge = edge;
 
-    // 4. the boundary lists of all ranks (ascending global ids) fix the rows of the per-substep all-gather
-    std::vector<uint32_t> counts(w);
-    {
-        std::vector<uint32_t> mine(n_local);
-        std::vector<const void *> send(n_local);
-        for (size_t k = 0; k < n_local; ++k) {
-            mine[k] = (uint32_t)mw->shards[k].boundary.size();
-            send[k] = &mine[k];
-        }
-        MW_TRY(all_gather_host(mw, send, 4, gathered));
-        std::memcpy(counts.data(), gathered.data(), (size_t)w * 4);
+    // 4. the boundary lists of all ranks (ascending global ids) fix the rows of the per-substep all-gather; the export lists
+    //    those of the plan-time record exchange
+    struct Counts {
+        uint32_t boundary, exports;
+    };
+    std::vector<Counts> mine(n_local), counts(w);
+    for (size_t k = 0; k < n_local; ++k) {
+        mine[k] = Counts{(uint32_t)mw->shards[k].boundary.size(), (uint32_t)exports[k].size()};
+        send[k] = &mine[k];
     }
-    mw->capacity = std::max(1u, *std::max_element(counts.begin(), counts.end()));
-    const uint32_t cap = mw->capacity;
+    MW_TRY(all_gather_host(mw, send, sizeof(Counts), gathered, st));
+    std::memcpy(counts.data(), gathered.data(), (size_t)w * sizeof(Counts));
+    uint32_t cap = 1, cap_exp = 0;
+    for (uint32_t r = 0; r < w; ++r) {
+        cap = std::max(cap, counts[r].boundary);
+        cap_exp = std::max(cap_exp, counts[r].exports);
+    }
+    mw->capacity = cap;
     std::vector<uint32_t> lists((size_t)w * cap);
-    std::vector<double> records((size_t)w * cap * kRecord);
     {
         std::vector<std::vector<uint32_t>> pad_list(n_local);
-        std::vector<std::vector<double>> pad_rec(n_local);
-        std::vector<const void *> send(n_local);
         for (size_t k = 0; k < n_local; ++k) {
             const Shard &s = mw->shards[k];
             pad_list[k].assign(cap, 0xFFFFFFFFu);
-            std::copy(s.boundary.begin(), s.boundary.end(), pad_list[k].begin());
+            if (st.ok())
+                std::copy(s.boundary.begin(), s.boundary.end(), pad_list[k].begin());
             send[k] = pad_list[k].data();
         }
-        MW_TRY(all_gather_host(mw, send, (size_t)cap * 4, gathered));
+        MW_TRY(all_gather_host(mw, send, (size_t)cap * 4, gathered, st));
         std::memcpy(lists.data(), gathered.data(), lists.size() * 4);
+    }
+    // the records of the exported bodies travel only when a holder may live in another process
+    const bool exchange_records = !mw->shortcut() && cap_exp > 0;
+    std::vector<uint32_t> exp_lists;
+    std::vector<double> exp_records;
+    if (exchange_records) {
+        std::vector<std::vector<uint32_t>> pad_list(n_local);
+        std::vector<std::vector<double>> pad_rec(n_local);
+        for (size_t k = 0; k < n_local; ++k) {
+            pad_list[k].assign(cap_exp, 0xFFFFFFFFu);
+            if (st.ok())
+                std::copy(exports[k].begin(), exports[k].end(), pad_list[k].begin());
+            send[k] = pad_list[k].data();
+        }
+        MW_TRY(all_gather_host(mw, send, (size_t)cap_exp * 4, gathered, st));
+        exp_lists.resize((size_t)w * cap_exp);
+        std::memcpy(exp_lists.data(), gathered.data(), exp_lists.size() * 4);
         for (size_t k = 0; k < n_local; ++k) {
             const Shard &s = mw->shards[k];
-            pad_rec[k].assign((size_t)cap * kRecord, 0.0);
-            for (size_t q = 0; q < s.boundary.size(); ++q) {
-                const uint32_t i = s.boundary[q] - s.own.first;
-                std::memcpy(&pad_rec[k][q * kRecord], &s.owned[(size_t)i * kRigid], kRigid * 8);
-                pad_rec[k][q * kRecord + kRigid] = (double)s.owned_sid[i];
+            pad_rec[k].assign((size_t)cap_exp * kRecord, 0.0);
+            for (size_t q = 0; q < exports[k].size() && st.ok(); ++q) {
+                const size_t i = std::lower_bound(s.held_ids.begin(), s.held_ids.end(), exports[k][q]) - s.held_ids.begin();
+                std::memcpy(&pad_rec[k][q * kRecord], &s.held[i * kRigid], kRigid * 8);
+                pad_rec[k][q * kRecord + kRigid] = (double)s.held_sid[i];
             }
             send[k] = pad_rec[k].data();
         }
-        MW_TRY(all_gather_host(mw, send, (size_t)cap * kRecord * 8, gathered));
-        std::memcpy(records.data(), gathered.data(), records.size() * 8);
+        MW_TRY(all_gather_host(mw, send, (size_t)cap_exp * kRecord * 8, gathered, st));
+        exp_records.resize((size_t)w * cap_exp * kRecord);
+        std::memcpy(exp_records.data(), gathered.data(), exp_records.size() * 8);
     }
 
-    // 5. every shard's local world: owned + ghost bodies in ascending global id
+    // 5. every shard's local world: owned + ghost bodies in ascending global id.  A body's record comes from the shard
+    //    itself if it holds the body, from another local shard (one process, several GPUs), or from the exchange.
     const uint32_t rows = mw->rows_per_rank();
-    for (Shard &s : mw->shards) {
-        MW_TRY(bind(s));
-        const uint32_t n_ghost = (uint32_t)s.ghosts.size(), n_loc = s.own.count + n_ghost;
-        std::vector<double> aos((size_t)n_loc * kRigid);
-        std::vector<uint32_t> sid(n_loc), ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(s.boundary.size()), owned_slots(s.own.count);
-        s.local_ids.resize(n_loc);
-        uint32_t slot = 0, gq = 0;
-        auto put_ghost = [&](uint32_t g) -> int {
-            const uint32_t o = owner_of(g, n, w);
-            const uint32_t *lo = &lists[(size_t)o * cap], *hi = lo + counts[o];
-            const uint32_t *at = std::lower_bound(lo, hi, g);
-            if (at == hi || *at != g)
-                return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is mirrored by rank %u but not exported by its owner %u (inconsistent plans)", g, s.rank, o);
-            const size_t row = (size_t)o * cap + (size_t)(at - lo);
-            std::memcpy(&aos[(size_t)slot * kRigid], &records[row * kRecord], kRigid * 8);
-            sid[slot] = (uint32_t)records[row * kRecord + kRigid];
-            ghost_slots[gq] = slot;
-            ghost_rows[gq] = o * rows + (uint32_t)(at - lo);
-            ++gq;
-            s.local_ids[slot++] = g;
+    auto record_of = [&](const Shard &me, uint32_t g, double *rec39) -> int {
+        const Shard *src = nullptr;
+        const uint32_t h = holder[g];
+        if (h == me.rank)
+            src = &me;
+        else if (!exchange_records)
+            src = mw->local_shard(h);
+        if (src) {
+            const auto at = std::lower_bound(src->held_ids.begin(), src->held_ids.end(), g);
+            if (at == src->held_ids.end() || *at != g)
+                return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is not among the bodies rank %u holds (inconsistent plans)", g, h);
+            const size_t i = at - src->held_ids.begin();
+            std::memcpy(rec39, &src->held[i * kRigid], kRigid * 8);
+            rec39[kRigid] = (double)src->held_sid[i];
             return XPBD_OK;
-        };
-        size_t gi = 0;
-        for (; gi < s.ghosts.size() && s.ghosts[gi] < s.own.first; ++gi)
-            MW_TRY(put_ghost(s.ghosts[gi]));
-        s.own_slot0 = slot;
-        if (s.own.count)
-            std::memcpy(&aos[(size_t)slot * kRigid], s.owned.data(), (size_t)s.own.count * kRigid * 8);
-        for (uint32_t i = 0; i < s.own.count; ++i) {
-            sid[slot] = s.owned_sid[i];
-            owned_slots[i] = slot;
-            s.local_ids[slot++] = s.own.first + i;
         }
-        for (; gi < s.ghosts.size(); ++gi)
-            MW_TRY(put_ghost(s.ghosts[gi]));
+        if (!exchange_records)
+            return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is held by rank %u, which is not in this process", g, h);
+        const uint32_t *lo = &exp_lists[(size_t)h * cap_exp], *hi = lo + counts[h].exports;
+        const uint32_t *at = std::lower_bound(lo, hi, g);
+        if (at == hi || *at != g)
+            return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is needed by rank %u but not exported by its holder %u (inconsistent plans)", g, me.rank, h);
+        std::memcpy(rec39, &exp_records[((size_t)h * cap_exp + (size_t)(at - lo)) * kRecord], kRecord * 8);
+        return XPBD_OK;
+    };
+    std::vector<std::vector<double>> new_held(n_local);
+    std::vector<std::vector<uint32_t>> new_sid(n_local);
+    auto build_shard = [&](size_t k) -> int {
+        Shard &s = mw->shards[k];
+        MW_TRY(bind(s));
+        const uint32_t n_own = (uint32_t)own[k].size(), n_ghost = (uint32_t)s.ghosts.size(), n_loc = n_own + n_ghost;
+        std::vector<double> aos((size_t)n_loc * kRigid);
+        std::vector<uint32_t> sid(n_loc), ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(s.boundary.size()), owned_slots(n_own);
+        s.local_ids.resize(n_loc);
+        new_held[k].resize((size_t)n_own * kRigid);
+        new_sid[k].resize(n_own);
+        uint32_t slot = 0, oi = 0, gi = 0;
+        double rec[kRecord];
+        while (oi < n_own || gi < n_ghost) {
+            const bool take_own = gi >= n_ghost || (oi < n_own && own[k][oi] < s.ghosts[gi]);
+            const uint32_t g = take_own ? own[k][oi] : s.ghosts[gi];
+            MW_TRY(record_of(s, g, rec));
+            std::memcpy(&aos[(size_t)slot * kRigid], rec, kRigid * 8);
+            sid[slot] = (uint32_t)rec[kRigid];
+            s.local_ids[slot] = g;
+            if (take_own) {
+                std::memcpy(&new_held[k][(size_t)oi * kRigid], rec, kRigid * 8);
+                new_sid[k][oi] = sid[slot];
+                owned_slots[oi++] = slot;
+            } else {
+                const uint32_t o = owner[g];
+                const uint32_t *lo = &lists[(size_t)o * cap], *hi = lo + counts[o].boundary;
+                const uint32_t *at = std::lower_bound(lo, hi, g);
+                if (at == hi || *at != g)
+                    return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is mirrored by rank %u but not exported by its owner %u (inconsistent plans)", g, s.rank, o);
+                ghost_slots[gi] = slot;
+                ghost_rows[gi] = o * rows + (uint32_t)(at - lo);
+                ++gi;
+            }
+            ++slot;
+        }
         for (size_t q = 0; q < s.boundary.size(); ++q)
-            boundary_slots[q] = s.own_slot0 + (s.boundary[q] - s.own.first);
+            boundary_slots[q] = owned_slots[std::lower_bound(own[k].begin(), own[k].end(), s.boundary[q]) - own[k].begin()];
         if (int rc = xpbd_world_upload_bodies(s.world, reinterpret_cast<const xpbd_rigid *>(aos.data()), sid.data(), n_loc))
             return rc;
         // joints whose two bodies are both present here, in global joint order, re-indexed to local slots
@@ -560,9 +838,9 @@ int make_plan(xpbd_multi_world *mw)
             skip[q] = 1;
         MW_TRY(upload_vector(s.skip_flags, skip, s.stream));
         // 1 / allowance^2 per owned body: the displacement check then yields the largest FRACTION of its allowance any body has used
-        std::vector<double> scale(s.own.count);
+        std::vector<double> scale(n_own);
         const double near_allow = mw->margin, far_allow = mw->margin + 0.5 * edge;
-        for (uint32_t i = 0; i < s.own.count; ++i) {
+        for (uint32_t i = 0; i < n_own; ++i) {
             const double allow = s.far[i] ? far_allow : near_allow;
             scale[i] = 1.0 / (allow * allow);
         }
@@ -570,13 +848,30 @@ int make_plan(xpbd_multi_world *mw)
         MW_HIP_TRY(s.send.reserve((size_t)rows * kDyn * 8));
         MW_HIP_TRY(s.recv.reserve((size_t)w * rows * kDyn * 8));
         MW_HIP_TRY(hipMemsetAsync(s.send.ptr, 0, (size_t)rows * kDyn * 8, s.stream));
-        MW_HIP_TRY(s.snapshot.reserve(std::max<size_t>((size_t)3 * s.own.count * 8, 8)));
-        MW_HIP_TRY(s.disp.reserve(8));
-        MW_HIP_TRY(s.disp_all.reserve((size_t)w * 8));
-        if (int rc = xpbd_world_snapshot_positions(s.world, s.owned_slots.as<uint32_t>(), s.own.count, s.snapshot.as<double>()))
+        MW_HIP_TRY(s.snapshot.reserve(std::max<size_t>((size_t)3 * n_own * 8, 8)));
+        MW_HIP_TRY(s.disp.reserve(16));
+        MW_HIP_TRY(s.disp_all.reserve((size_t)w * 16));
+        if (int rc = xpbd_world_snapshot_positions(s.world, s.owned_slots.as<uint32_t>(), n_own, s.snapshot.as<double>()))
             return rc;
         MW_HIP_TRY(hipStreamSynchronize(s.stream)); // the host vectors above go out of scope
+        s.owned_slots_h.swap(owned_slots);
+        return XPBD_OK;
+    };
+    for (size_t k = 0; k < n_local && st.ok(); ++k)
+        st.keep(build_shard(k));
+    // all ranks leave the plan together: a last status-only exchange (a failed upload on one rank fails the plan everywhere)
+    for (size_t k = 0; k < n_local; ++k)
+        send[k] = nullptr;
+    MW_TRY(all_gather_host(mw, send, 0, gathered, st));
+    for (size_t k = 0; k < n_local; ++k) { // from now on the shards hold what they own
+        Shard &s = mw->shards[k];
+        s.held_ids.swap(own[k]);
+        s.held.swap(new_held[k]);
+        s.held_sid.swap(new_sid[k]);
     }
+    mw->owner.swap(owner);
+    mw->owned_count.swap(owned_count);
+    mw->migrated = migrated;
     mw->planned = true;
     mw->violated = false;
     mw->last_displacement = 0.0;
@@ -584,7 +879,7 @@ int make_plan(xpbd_multi_world *mw)
     return XPBD_OK;
 }
 
-// The owned bodies' current state back into Shard::owned (for a re-plan or a download).
+// The owned bodies' current state back into Shard::held (for a re-plan or a download).
 int fetch_owned(xpbd_multi_world *mw)
 {
     for (Shard &s : mw->shards) {
@@ -593,34 +888,163 @@ int fetch_owned(xpbd_multi_world *mw)
         std::vector<double> aos((size_t)n_loc * kRigid);
         if (int rc = xpbd_world_download_bodies(s.world, reinterpret_cast<xpbd_rigid *>(aos.data()), n_loc))
             return rc;
-        if (s.own.count)
-            std::memcpy(s.owned.data(), &aos[(size_t)s.own_slot0 * kRigid], (size_t)s.own.count * kRigid * 8);
+        for (size_t i = 0; i < s.held_ids.size(); ++i)
+            std::memcpy(&s.held[i * kRigid], &aos[(size_t)s.owned_slots_h[i] * kRigid], kRigid * 8);
     }
     return XPBD_OK;
 }
 
-// Largest fraction of its travel allowance any owned body of any rank has used since the plan, agreed on by all ranks and
-// expressed in margin-equivalent metres (x halo_margin): a body next to a shard boundary may travel halo_margin, one more
-// than two cells away from every foreign body halo_margin + half a cell edge (HaloPlanner::plan_rank).
-int measure_displacement(xpbd_multi_world *mw, double *out)
+int replan(xpbd_multi_world *mw)
 {
-    for (Shard &s : mw->shards) {
-        MW_TRY(bind(s));
-        MW_HIP_TRY(hipMemsetAsync(s.disp.ptr, 0, 8, s.stream));
-        if (int rc = xpbd_world_max_displacement2(s.world, s.owned_slots.as<uint32_t>(), s.own.count, s.snapshot.as<double>(), s.disp_scale.as<double>(),
-                                                  s.disp.as<double>()))
-            return rc;
+    LocalStatus st;
+    st.keep(fetch_owned(mw));
+    if (!st.ok()) { // the plan's first collective tells the others
+        std::vector<const void *> send(mw->shards.size(), nullptr);
+        std::vector<uint8_t> gathered;
+        struct Head {
+            double rmax;
+            uint64_t count;
+        } dummy{0.0, 0};
+        for (auto &p : send)
+            p = &dummy;
+        return all_gather_host(mw, send, sizeof dummy, gathered, st);
     }
-    MW_TRY(all_gather_device(mw, 8, [](Shard &s) { return s.disp.ptr; }, [](Shard &s) { return s.disp_all.ptr; })); // 8 bytes per rank
+    return make_plan(mw);
+}
+
+// Enqueues one whole frame on every local shard and, behind it, the end-of-frame exchange: per rank the largest fraction of
+// its travel allowance any owned body has used since the plan (squared) and the rank's status.  Local errors are kept in
+// `st` (the remaining local launches are skipped, the collectives still run); only a failing collective returns at once.
+int enqueue_frame(xpbd_multi_world *mw, double dt, uint32_t substeps, LocalStatus &st)
+{
+    const bool multi = mw->n_ranks > 1;
+    const double h = dt / (double)substeps; // src/solver.rs:4
+    const uint64_t t0 = now_ns();
+    if (multi)
+        for (Shard &s : mw->shards)
+            if (st.ok())
+                st.keep(xpbd::frame_snapshot_save(s.world));
+    // the broadphase of ALL shards is on its way before the host waits for any of them
+    for (Shard &s : mw->shards)
+        if (st.ok())
+            st.keep(xpbd::halo_frame_begin_enqueue(s.world, dt));
+    const uint64_t t1 = now_ns();
+    for (Shard &s : mw->shards)
+        if (st.ok())
+            st.keep(xpbd::halo_frame_begin_collect(s.world, h));
+    const uint64_t t2 = now_ns();
+    mw->ns_wait_broadphase += t2 - t1;
+    const size_t bytes = (size_t)mw->rows_per_rank() * kDyn * 8;
+    auto lists_of = [](Shard &s) {
+        return xpbd::HaloLists{s.boundary_slots.as<uint32_t>(), (uint32_t)s.boundary.size(), s.ghost_slots.as<uint32_t>(), s.ghost_rows.as<uint32_t>(),
+                               (uint32_t)s.ghosts.size(), s.skip_flags.as<uint8_t>(), s.send.as<double>(), s.recv.as<double>()};
+    };
+    auto hip_keep = [&st](hipError_t e, const char *what) {
+        if (e != hipSuccess)
+            st.keep(set_error(XPBD_E_HIP, "%s failed: %s", what, hipGetErrorString(e)));
+    };
+    for (uint32_t k = 0; k < substeps; ++k) {
+        const bool last = k + 1 == substeps;
+        // 1. the narrowphase, then the boundary bodies: their end-of-substep state lands in the send buffer
+        for (Shard &s : mw->shards) {
+            if (st.ok())
+                st.keep(xpbd::halo_substep_boundary(s.world, h, k, last, lists_of(s)));
+            if (multi) {
+                st.keep(bind(s));
+                hip_keep(hipEventRecord(s.ev_ready, s.stream), "hipEventRecord");
+                hip_keep(hipStreamWaitEvent(s.comm_stream, s.ev_ready, 0), "hipStreamWaitEvent");
+            }
+        }
+        // 2. ONE all-gather per substep on the communication streams ...
+        if (multi) {
+            MW_TRY(all_gather_device(mw, bytes, [](Shard &s) { return s.send.ptr; }, [](Shard &s) { return s.recv.ptr; }, true));
+            for (Shard &s : mw->shards) {
+                st.keep(bind(s));
+                hip_keep(hipEventRecord(s.ev_gathered, s.comm_stream), "hipEventRecord");
+            }
+        }
+        // 3. ... while the interior bodies (nobody mirrors them) run on the world streams
+        for (Shard &s : mw->shards)
+            if (st.ok())
+                st.keep(xpbd::halo_substep_interior(s.world, h, k, last, lists_of(s)));
+        // 4. the ghosts take their owners' state from the gathered buffer
+        if (multi)
+            for (Shard &s : mw->shards) {
+                st.keep(bind(s));
+                hip_keep(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), "hipStreamWaitEvent");
+                if (st.ok())
+                    st.keep(xpbd::halo_substep_ghosts(s.world, h, k, last, lists_of(s)));
+                // the next substep's boundary launch rewrites the send buffer: not before this exchange has read it
+                // (the communication stream is in order, so waiting for ev_gathered above covers the own copy; the peers'
+                // reads of OUR buffer are ordered by the transport: RCCL completes the collective, the in-process
+                // transport makes the communication streams wait for every peer's ev_recv)
+            }
+    }
+    if (multi) {
+        // halo validity of THIS frame and the ranks' status, agreed on by all ranks
+        for (Shard &s : mw->shards) {
+            st.keep(bind(s));
+            hip_keep(hipMemsetAsync(s.disp.ptr, 0, 16, s.stream), "hipMemsetAsync");
+            if (st.ok())
+                st.keep(xpbd_world_max_displacement2(s.world, s.owned_slots.as<uint32_t>(), (uint32_t)s.held_ids.size(), s.snapshot.as<double>(),
+                                                     s.disp_scale.as<double>(), s.disp.as<double>()));
+        }
+        for (Shard &s : mw->shards) { // (after the last local launch that could still fail)
+            (void)hipSetDevice(s.device);
+            *s.status_host = (double)st.rc;
+            hip_keep(hipMemcpyAsync(s.disp.as<double>() + 1, s.status_host, 8, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+        }
+        MW_TRY(all_gather_device(mw, 16, [](Shard &s) { return s.disp.ptr; }, [](Shard &s) { return s.disp_all.ptr; }));
+        for (Shard &s : mw->shards) {
+            (void)hipSetDevice(s.device);
+            hip_keep(hipMemcpyAsync(s.disp_host, s.disp_all.ptr, (size_t)mw->n_ranks * 16, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+        }
+    }
+    mw->ns_enqueue += (now_ns() - t0) - (t2 - t1);
+    return XPBD_OK;
+}
+
+// Waits for the frame's last exchange.  *moved = the largest fraction of its travel allowance any owned body of any rank
+// has used since the plan, in margin-equivalent metres (x halo_margin): a body next to a shard boundary may travel
+// halo_margin, one more than two cells away from every foreign body halo_margin + half a cell edge (HaloPlanner::plan_rank).
+// Returns the error all ranks agree on, if any rank had one.
+int finish_frame(xpbd_multi_world *mw, LocalStatus &st, double *moved)
+{
+    const uint64_t t0 = now_ns();
     double worst = 0.0;
+    int64_t peer_rc = 0;
+    uint32_t peer = 0;
     for (Shard &s : mw->shards) {
-        MW_TRY(bind(s));
-        MW_HIP_TRY(hipMemcpyAsync(s.disp_host, s.disp_all.ptr, (size_t)mw->n_ranks * 8, hipMemcpyDeviceToHost, s.stream));
-        MW_HIP_TRY(hipStreamSynchronize(s.stream));
-        for (uint32_t r = 0; r < mw->n_ranks; ++r)
-            worst = std::max(worst, s.disp_host[r]);
+        (void)hipSetDevice(s.device);
+        const hipError_t e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess)
+            return transport_broken(mw, set_error(XPBD_E_HIP, "xpbd_multi_world_step: hipStreamSynchronize failed: %s", hipGetErrorString(e)));
+        for (uint32_t r = 0; r < mw->n_ranks; ++r) {
+            const double d = s.disp_host[2 * r], code = s.disp_host[2 * r + 1];
+            if (d != d) // (the kernel already counts a NaN position as +inf)
+                worst = INFINITY;
+            else if (d > worst)
+                worst = d;
+            if (code != 0.0 && peer_rc == 0) {
+                peer_rc = (int64_t)code;
+                peer = r;
+            }
+        }
     }
-    *out = std::sqrt(worst) * mw->margin; // "margin-equivalent" metres: halo_margin means the allowance is used up
+    mw->ns_wait_frame += now_ns() - t0;
+    *moved = std::sqrt(worst) * mw->margin; // "margin-equivalent" metres: halo_margin means the allowance is used up
+    if (!st.ok())
+        return st.report();
+    if (peer_rc != 0)
+        return set_error((int)peer_rc, "xpbd_multi_world_step: rank %u failed with error %d in this frame (see its xpbd_last_error); the frame "
+                                       "is undone on every rank", peer, (int)peer_rc);
+    return XPBD_OK;
+}
+
+int restore_frame(xpbd_multi_world *mw)
+{
+    for (Shard &s : mw->shards)
+        MW_TRY(xpbd::frame_snapshot_restore(s.world));
     return XPBD_OK;
 }
 
@@ -638,6 +1062,8 @@ void destroy(xpbd_multi_world *mw)
             b->release();
         if (s.disp_host)
             (void)hipHostFree(s.disp_host);
+        if (s.status_host)
+            (void)hipHostFree(s.status_host);
         if (s.comm_stream)
             (void)hipStreamDestroy(s.comm_stream);
         if (s.ev_send)
@@ -651,6 +1077,15 @@ void destroy(xpbd_multi_world *mw)
         xpbd_world_destroy(s.world);
     }
     delete mw;
+}
+
+int check_usable(const xpbd_multi_world *mw, const char *who)
+{
+    if (!mw)
+        return set_error(XPBD_E_INVALID, "%s: NULL world", who);
+    if (mw->broken)
+        return set_error(XPBD_E_HIP, "%s: a collective of this world failed earlier; destroy it on every rank", who);
+    return XPBD_OK;
 }
 
 } // namespace
@@ -702,6 +1137,8 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
     *out = nullptr;
     if (cfg->struct_size != sizeof(xpbd_multi_config))
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: struct_size %u != %zu", cfg->struct_size, sizeof(xpbd_multi_config));
+    if (cfg->reserved != 0)
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: reserved must be 0");
     if (cfg->n_ranks == 0 || cfg->n_ranks > 64 || cfg->n_local == 0 || cfg->first_rank + cfg->n_local > cfg->n_ranks || !cfg->devices)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: ranks [%u, %u) of %u (at most 64) and a device list are needed", cfg->first_rank,
                          cfg->first_rank + cfg->n_local, cfg->n_ranks);
@@ -755,7 +1192,8 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_gathered, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.disp_host), (size_t)cfg->n_ranks * 8, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.disp_host), (size_t)cfg->n_ranks * 16, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.status_host), 8, hipHostMallocDefault);
         if (e != hipSuccess)
             return bail(set_error(XPBD_E_HIP, "xpbd_multi_world_create: %s", hipGetErrorString(e)));
     }
@@ -764,16 +1202,21 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
         std::memcpy(&id, cfg->comm_id, sizeof id);
         (void)hipGetLastError(); // see all_gather_device
         ncclResult_t r = mw->rccl->GroupStart();
+        bool device_failed = false;
+        int failed_device = 0;
         for (Shard &s : mw->shards) {
             if (r != ncclSuccess)
                 break;
             if (hipSetDevice(s.device) != hipSuccess) {
-                (void)mw->rccl->GroupEnd();
-                return bail(set_error(XPBD_E_HIP, "xpbd_multi_world_create: hipSetDevice(%d) failed", s.device));
+                device_failed = true;
+                failed_device = s.device;
+                break;
             }
             r = mw->rccl->CommInitRank(&s.comm, (int)mw->n_ranks, id, (int)s.rank);
         }
         const ncclResult_t r_end = mw->rccl->GroupEnd();
+        if (device_failed)
+            return bail(set_error(XPBD_E_HIP, "xpbd_multi_world_create: hipSetDevice(%d) failed", failed_device));
         if (r == ncclSuccess)
             r = r_end;
         if (r != ncclSuccess)
@@ -789,6 +1232,9 @@ int xpbd_multi_world_set_polytopes(xpbd_multi_world *mw, const xpbd_polytope *sh
 {
     if (!mw || !shapes || n_shapes == 0)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_set_polytopes: NULL argument or no shapes");
+    // validated by the first shard before any shard changes; a later failure leaves the world without shapes (and says so)
+    mw->have_shapes = false;
+    mw->planned = false;
     for (Shard &s : mw->shards)
         if (int rc = xpbd_world_set_polytopes(s.world, shapes, n_shapes))
             return rc;
@@ -808,20 +1254,21 @@ int xpbd_multi_world_set_polytopes(xpbd_multi_world *mw, const xpbd_polytope *sh
         }
     }
     mw->have_shapes = true;
-    mw->planned = false;
     return XPBD_OK;
 }
 
 int xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, const uint32_t *shape_id, uint32_t first_global, uint32_t n_bodies,
                             uint32_t n_global, const xpbd_joint *joints, uint32_t n_joints)
 {
-    if (!mw || (n_bodies && !bodies) || (n_joints && !joints))
+    MW_TRY(check_usable(mw, "xpbd_multi_world_upload"));
+    // Argument errors are found by every rank alike (or are the caller's to agree on): they return before any collective.
+    if ((n_bodies && !bodies) || (n_joints && !joints))
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_upload: NULL argument");
     if (!mw->have_shapes)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_upload: call xpbd_multi_world_set_polytopes first");
     const Range lo = shard_range(n_global, mw->first_rank, mw->n_ranks), hi = shard_range(n_global, mw->first_rank + (uint32_t)mw->shards.size() - 1, mw->n_ranks);
     if (first_global != lo.first || n_bodies != hi.first + hi.count - lo.first)
-        return set_error(XPBD_E_INVALID, "xpbd_multi_world_upload: ranks [%u, %u) of %u own bodies [%u, %u) of %u, got [%u, %u)", mw->first_rank,
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_upload: ranks [%u, %u) of %u hand over bodies [%u, %u) of %u, got [%u, %u)", mw->first_rank,
                          mw->first_rank + (uint32_t)mw->shards.size(), mw->n_ranks, lo.first, hi.first + hi.count, n_global, first_global,
                          first_global + n_bodies);
     const size_t n_shapes = mw->shape_radius.size();
@@ -833,103 +1280,78 @@ int xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, cons
             return set_error(XPBD_E_INVALID, "xpbd_multi_world_upload: joint %u links bodies %u and %u of %u", j, joints[j].body_a, joints[j].body_b, n_global);
     mw->n_global = n_global, mw->first_global = first_global, mw->n_bodies = n_bodies;
     mw->joints.assign(joints, joints + n_joints);
+    mw->planned = false;
     for (Shard &s : mw->shards) {
-        s.own = shard_range(n_global, s.rank, mw->n_ranks);
-        s.owned.resize((size_t)s.own.count * kRigid);
-        s.owned_sid.assign(s.own.count, 0);
-        if (s.own.count) {
-            std::memcpy(s.owned.data(), bodies + (s.own.first - first_global), (size_t)s.own.count * sizeof(xpbd_rigid));
+        const Range slice = shard_range(n_global, s.rank, mw->n_ranks);
+        s.held_ids.resize(slice.count);
+        s.held.resize((size_t)slice.count * kRigid);
+        s.held_sid.assign(slice.count, 0);
+        for (uint32_t i = 0; i < slice.count; ++i)
+            s.held_ids[i] = slice.first + i;
+        if (slice.count) {
+            std::memcpy(s.held.data(), bodies + (slice.first - first_global), (size_t)slice.count * sizeof(xpbd_rigid));
             if (shape_id)
-                std::memcpy(s.owned_sid.data(), shape_id + (s.own.first - first_global), (size_t)s.own.count * 4);
+                std::memcpy(s.held_sid.data(), shape_id + (slice.first - first_global), (size_t)slice.count * 4);
         }
     }
     mw->plans = 0;
+    mw->rollbacks = 0;
     return make_plan(mw);
 }
 
 int xpbd_multi_world_replan(xpbd_multi_world *mw)
 {
-    if (!mw || !mw->planned)
+    MW_TRY(check_usable(mw, "xpbd_multi_world_replan"));
+    if (!mw->planned)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_replan: no bodies uploaded");
-    MW_TRY(fetch_owned(mw));
-    return make_plan(mw);
+    return replan(mw);
 }
 
 int xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps)
 {
-    if (!mw)
-        return set_error(XPBD_E_INVALID, "xpbd_multi_world_step: NULL world");
+    MW_TRY(check_usable(mw, "xpbd_multi_world_step"));
     if (substeps == 0)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_step: substeps must be > 0");
     if (!mw->planned)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_step: no bodies uploaded");
     if (mw->violated)
-        return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body has used up its travel allowance since the halos were planned (%.3g m in "
-                                      "margin-equivalent metres, halo_margin %.3g m): remote contacts may have been missed -- call "
-                                      "xpbd_multi_world_replan (and re-plan more often or raise the margin)",
-                         mw->last_displacement, mw->margin);
-    // halo validity, agreed on by all ranks, before anything is stepped
-    if (mw->n_ranks > 1) {
+        return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body used up its travel allowance within the last frame (%.3g m in margin-equivalent "
+                                      "metres, halo_margin %.3g m); that frame was undone -- call xpbd_multi_world_replan (and re-plan more often "
+                                      "or raise the margin)", mw->last_displacement, mw->margin);
+    ++mw->steps;
+    for (int attempt = 0;; ++attempt) {
+        LocalStatus st;
+        MW_TRY(enqueue_frame(mw, dt, substeps, st));
+        if (mw->n_ranks == 1)
+            return st.ok() ? XPBD_OK : st.report(); // no ghosts, nothing to validate: asynchronous after the broadphase
         double moved = 0.0;
-        MW_TRY(measure_displacement(mw, &moved));
+        if (int rc = finish_frame(mw, st, &moved)) {
+            if (mw->broken)
+                return rc;
+            const std::string msg = xpbd_last_error();
+            (void)restore_frame(mw); // best effort: the state of the frame's start, on every rank
+            return set_error(rc, "%s", msg.c_str());
+        }
         mw->last_displacement = moved;
-        if (!(moved <= mw->margin)) {
+        if (moved <= mw->margin) {
+            // pre-emptive: half the allowance is gone, so re-plan (and re-balance) from the state just reached
+            if ((mw->flags & XPBD_MULTI_AUTO_REPLAN) && moved > 0.5 * mw->margin)
+                MW_TRY(replan(mw));
+            return XPBD_OK;
+        }
+        // A body outran its allowance during THIS frame: a remote contact may have been missed in it.  Undo the frame.
+        MW_TRY(restore_frame(mw));
+        ++mw->rollbacks;
+        if (!(mw->flags & XPBD_MULTI_AUTO_REPLAN) || attempt == 1) {
             mw->violated = true;
-            return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body has used up its travel allowance since the halos were planned (%.3g m in "
-                                          "margin-equivalent metres, beyond halo_margin %.3g m): remote contacts may have been missed in the "
-                                          "last frame -- call xpbd_multi_world_replan",
-                             moved, mw->margin);
+            return set_error(XPBD_E_HALO, "xpbd_multi_world_step: a body used up its travel allowance during this frame (%.3g m in "
+                                          "margin-equivalent metres, beyond halo_margin %.3g m%s): remote contacts may have been missed, so the "
+                                          "frame was undone -- call xpbd_multi_world_replan and step again%s",
+                             moved, mw->margin, attempt ? ", even right after a re-plan" : "",
+                             attempt ? " with a larger halo_margin or a shorter frame" : "");
         }
-        if ((mw->flags & XPBD_MULTI_AUTO_REPLAN) && moved > 0.5 * mw->margin)
-            MW_TRY(xpbd_multi_world_replan(mw));
+        MW_TRY(replan(mw)); // from the restored state; then the same frame again
     }
-    const double h = dt / (double)substeps; // src/solver.rs:4
-    for (Shard &s : mw->shards)
-        if (int rc = xpbd::halo_frame_begin(s.world, dt, h))
-            return rc;
-    const size_t bytes = (size_t)mw->rows_per_rank() * kDyn * 8;
-    auto lists_of = [](Shard &s) {
-        return xpbd::HaloLists{s.boundary_slots.as<uint32_t>(), (uint32_t)s.boundary.size(), s.ghost_slots.as<uint32_t>(), s.ghost_rows.as<uint32_t>(),
-                               (uint32_t)s.ghosts.size(), s.skip_flags.as<uint8_t>(), s.send.as<double>(), s.recv.as<double>()};
-    };
-    for (uint32_t k = 0; k < substeps; ++k) {
-        const bool last = k + 1 == substeps;
-        // 1. the narrowphase, then the boundary bodies: their end-of-substep state lands in the send buffer
-        for (Shard &s : mw->shards) {
-            if (int rc = xpbd::halo_substep_boundary(s.world, h, k, last, lists_of(s)))
-                return rc;
-            if (mw->n_ranks > 1) {
-                MW_TRY(bind(s));
-                MW_HIP_TRY(hipEventRecord(s.ev_ready, s.stream));
-                MW_HIP_TRY(hipStreamWaitEvent(s.comm_stream, s.ev_ready, 0));
-            }
-        }
-        // 2. ONE all-gather per substep on the communication streams ...
-        if (mw->n_ranks > 1) {
-            MW_TRY(all_gather_device(mw, bytes, [](Shard &s) { return s.send.ptr; }, [](Shard &s) { return s.recv.ptr; }, true));
-            for (Shard &s : mw->shards) {
-                MW_TRY(bind(s));
-                MW_HIP_TRY(hipEventRecord(s.ev_gathered, s.comm_stream));
-            }
-        }
-        // 3. ... while the interior bodies (nobody mirrors them) run on the world streams
-        for (Shard &s : mw->shards)
-            if (int rc = xpbd::halo_substep_interior(s.world, h, k, last, lists_of(s)))
-                return rc;
-        // 4. the ghosts take their owners' state from the gathered buffer
-        if (mw->n_ranks > 1)
-            for (Shard &s : mw->shards) {
-                MW_TRY(bind(s));
-                MW_HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
-                if (int rc = xpbd::halo_substep_ghosts(s.world, h, k, last, lists_of(s)))
-                    return rc;
-                // the next substep's boundary launch rewrites the send buffer: not before this exchange has read it
-                // (the communication stream is in order, so waiting for ev_gathered above covers the own copy; the peers'
-                // reads of OUR buffer are ordered by the transport: RCCL completes the collective, the in-process
-                // transport makes the communication streams wait for every peer's ev_recv)
-            }
-    }
-    return XPBD_OK;
 }
 
 int xpbd_multi_world_synchronize(xpbd_multi_world *mw)
@@ -942,16 +1364,80 @@ int xpbd_multi_world_synchronize(xpbd_multi_world *mw)
     return XPBD_OK;
 }
 
+int xpbd_multi_world_download_owned(xpbd_multi_world *mw, uint32_t *ids, xpbd_rigid *out, uint32_t cap, uint32_t *n_out)
+{
+    MW_TRY(check_usable(mw, "xpbd_multi_world_download_owned"));
+    if (!n_out || (cap && (!ids || !out)))
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_download_owned: NULL argument");
+    if (!mw->planned)
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_download_owned: no bodies uploaded");
+    size_t total = 0;
+    for (const Shard &s : mw->shards)
+        total += s.held_ids.size();
+    *n_out = (uint32_t)total;
+    if (total > cap)
+        return set_error(XPBD_E_CAPACITY, "xpbd_multi_world_download_owned: %zu owned bodies, capacity %u", total, cap);
+    MW_TRY(fetch_owned(mw));
+    size_t at = 0;
+    for (const Shard &s : mw->shards) {
+        if (s.held_ids.empty())
+            continue;
+        std::memcpy(ids + at, s.held_ids.data(), s.held_ids.size() * 4);
+        std::memcpy(out + at, s.held.data(), s.held_ids.size() * sizeof(xpbd_rigid));
+        at += s.held_ids.size();
+    }
+    return XPBD_OK;
+}
+
 int xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n)
 {
-    if (!mw || (n && !out))
+    MW_TRY(check_usable(mw, "xpbd_multi_world_download"));
+    if (n && !out)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_download: NULL argument");
     if (!mw->planned || n != mw->n_bodies)
-        return set_error(XPBD_E_INVALID, "xpbd_multi_world_download: n = %u but this process owns %u bodies", n, mw->planned ? mw->n_bodies : 0);
-    MW_TRY(fetch_owned(mw));
-    for (const Shard &s : mw->shards)
-        if (s.own.count)
-            std::memcpy(out + (s.own.first - mw->first_global), s.owned.data(), (size_t)s.own.count * sizeof(xpbd_rigid));
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_download: n = %u but this process handed over %u bodies", n, mw->planned ? mw->n_bodies : 0);
+    LocalStatus st;
+    st.keep(fetch_owned(mw));
+    const uint32_t lo = mw->first_global, hi = mw->first_global + mw->n_bodies;
+    if (mw->shortcut()) { // every owner is here
+        if (!st.ok())
+            return st.report();
+        for (const Shard &s : mw->shards)
+            for (size_t i = 0; i < s.held_ids.size(); ++i)
+                std::memcpy(out + (s.held_ids[i] - lo), &s.held[i * kRigid], sizeof(xpbd_rigid));
+        return XPBD_OK;
+    }
+    // one all-gather of every rank's owned bodies (id + state); each process keeps the slice it handed over
+    uint32_t cap = 0;
+    for (uint32_t c : mw->owned_count)
+        cap = std::max(cap, c);
+    const size_t row = 4 + (size_t)kRigid * 8, n_local = mw->shards.size();
+    std::vector<std::vector<uint8_t>> payload(n_local);
+    std::vector<const void *> send(n_local);
+    for (size_t k = 0; k < n_local; ++k) {
+        const Shard &s = mw->shards[k];
+        payload[k].assign((size_t)cap * row, 0xFF);
+        for (size_t i = 0; i < s.held_ids.size(); ++i) {
+            std::memcpy(&payload[k][i * row], &s.held_ids[i], 4);
+            std::memcpy(&payload[k][i * row + 4], &s.held[i * kRigid], kRigid * 8);
+        }
+        send[k] = payload[k].data();
+    }
+    std::vector<uint8_t> gathered;
+    MW_TRY(all_gather_host(mw, send, (size_t)cap * row, gathered, st));
+    uint32_t found = 0;
+    for (uint32_t r = 0; r < mw->n_ranks; ++r)
+        for (uint32_t i = 0; i < mw->owned_count[r]; ++i) {
+            const uint8_t *p = gathered.data() + ((size_t)r * cap + i) * row;
+            uint32_t g;
+            std::memcpy(&g, p, 4);
+            if (g >= lo && g < hi) {
+                std::memcpy(out + (g - lo), p + 4, sizeof(xpbd_rigid));
+                ++found;
+            }
+        }
+    if (found != mw->n_bodies)
+        return set_error(XPBD_E_HIP, "xpbd_multi_world_download: %u of the %u bodies of this process came back", found, mw->n_bodies);
     return XPBD_OK;
 }
 
@@ -961,13 +1447,37 @@ int xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *m
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_halo_stats: NULL argument");
     uint64_t owned = 0, ghosts = 0, boundary = 0;
     for (const Shard &s : mw->shards) {
-        owned += s.own.count;
+        owned += s.held_ids.size();
         ghosts += s.ghosts.size();
         boundary += s.boundary.size();
     }
     out[0] = mw->n_global, out[1] = owned, out[2] = ghosts, out[3] = boundary, out[4] = mw->capacity, out[5] = mw->plans;
     if (max_displacement)
         *max_displacement = mw->last_displacement;
+    return XPBD_OK;
+}
+
+int xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10])
+{
+    if (!mw || !out)
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_plan_stats: NULL argument");
+    uint32_t lo = UINT32_MAX, hi = 0;
+    for (uint32_t c : mw->owned_count) {
+        lo = std::min(lo, c);
+        hi = std::max(hi, c);
+    }
+    out[0] = mw->plans, out[1] = mw->rollbacks, out[2] = mw->migrated, out[3] = mw->owned_count.empty() ? 0 : lo, out[4] = hi;
+    out[5] = mw->steps, out[6] = mw->ns_enqueue, out[7] = mw->ns_wait_broadphase, out[8] = mw->ns_wait_frame, out[9] = 0;
+    return XPBD_OK;
+}
+
+int xpbd_multi_world_owners(xpbd_multi_world *mw, uint8_t *owner, uint32_t n_global)
+{
+    if (!mw || !owner)
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_owners: NULL argument");
+    if (!mw->planned || n_global != mw->n_global)
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_owners: n_global = %u but the world has %u bodies", n_global, mw->planned ? mw->n_global : 0);
+    std::memcpy(owner, mw->owner.data(), n_global);
     return XPBD_OK;
 }
 
@@ -986,33 +1496,78 @@ int xpbd_multi_world_contact_stats(xpbd_multi_world *mw, uint64_t out[3])
     return XPBD_OK;
 }
 
-// Diagnostics (host only, no device): the halo plan of one rank from the global cell keys, as make_plan computes it.
+// Diagnostics (host only, no device): ownership and halo plans from the global cell keys, as make_plan computes them.
+int xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint8_t *owner)
+{
+    if ((n_global && (!cell_keys || !owner)) || n_ranks == 0 || n_ranks > 64)
+        return set_error(XPBD_E_INVALID, "xpbd_halo_partition: bad argument");
+    std::vector<Cut> cuts;
+    partition_cuts(cell_keys, n_global, n_ranks, cuts);
+    for (uint32_t g = 0; g < n_global; ++g)
+        owner[g] = (uint8_t)owner_of(cuts, cell_keys[g], g);
+    return XPBD_OK;
+}
+
+int xpbd_halo_plan_owned(const int64_t *cell_keys, const uint8_t *owner, uint32_t n_global, uint32_t n_ranks, uint32_t rank, const xpbd_joint *joints,
+                         uint32_t n_joints, uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary, uint32_t *n_boundary, uint8_t *far, uint32_t cap)
+{
+    if (!cell_keys || !owner || !n_ghosts || !n_boundary || n_ranks == 0 || n_ranks > 64 || rank >= n_ranks || (n_joints && !joints) ||
+        (cap && (!ghosts || !boundary)))
+        return set_error(XPBD_E_INVALID, "xpbd_halo_plan_owned: bad argument");
+    for (uint32_t g = 0; g < n_global; ++g)
+        if (owner[g] >= n_ranks)
+            return set_error(XPBD_E_INVALID, "xpbd_halo_plan_owned: owner[%u] = %u of %u ranks", g, owner[g], n_ranks);
+    for (uint32_t j = 0; j < n_joints; ++j)
+        if (joints[j].body_a >= n_global || joints[j].body_b >= n_global)
+            return set_error(XPBD_E_INVALID, "xpbd_halo_plan_owned: joint %u names a body out of range", j);
+    HaloPlanner planner;
+    planner.n = n_global, planner.w = n_ranks, planner.keys = cell_keys, planner.owner = owner;
+    std::vector<uint32_t> own, g, b;
+    std::vector<uint8_t> f;
+    planner.plan_rank(rank, joints, n_joints, own, g, b, far ? &f : nullptr);
+    *n_ghosts = (uint32_t)g.size(), *n_boundary = (uint32_t)b.size();
+    if (g.size() > cap || b.size() > cap || (far && f.size() > cap))
+        return set_error(XPBD_E_CAPACITY, "xpbd_halo_plan_owned: %zu ghosts, %zu boundary bodies, %zu owned, capacity %u", g.size(), b.size(), own.size(), cap);
+    std::copy(g.begin(), g.end(), ghosts);
+    std::copy(b.begin(), b.end(), boundary);
+    if (far)
+        std::copy(f.begin(), f.end(), far); // one flag per owned body, in ascending id
+    return XPBD_OK;
+}
+
+namespace {
+void range_owners(uint32_t n_global, uint32_t n_ranks, std::vector<uint8_t> &owner)
+{
+    owner.resize(n_global);
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const Range rr = shard_range(n_global, r, n_ranks);
+        std::fill(owner.begin() + rr.first, owner.begin() + rr.first + rr.count, (uint8_t)r);
+    }
+}
+} // namespace
+
+// ... with ownership by contiguous index ranges (what a caller that orders its bodies itself would get)
 int xpbd_halo_plan(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, const xpbd_joint *joints, uint32_t n_joints,
                    uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary, uint32_t *n_boundary, uint32_t cap)
 {
-    if (!cell_keys || !n_ghosts || !n_boundary || n_ranks == 0 || n_ranks > 64 || rank >= n_ranks || (n_joints && !joints) || (cap && (!ghosts || !boundary)))
+    if (n_ranks == 0 || n_ranks > 64)
         return set_error(XPBD_E_INVALID, "xpbd_halo_plan: bad argument");
-    HaloPlanner planner;
-    planner.n = n_global, planner.w = n_ranks, planner.keys = cell_keys;
-    std::vector<uint32_t> g, b;
-    planner.plan_rank(rank, joints, n_joints, g, b);
-    *n_ghosts = (uint32_t)g.size(), *n_boundary = (uint32_t)b.size();
-    if (g.size() > cap || b.size() > cap)
-        return set_error(XPBD_E_CAPACITY, "xpbd_halo_plan: %zu ghosts, %zu boundary bodies, capacity %u", g.size(), b.size(), cap);
-    std::copy(g.begin(), g.end(), ghosts);
-    std::copy(b.begin(), b.end(), boundary);
-    return XPBD_OK;
+    std::vector<uint8_t> owner;
+    range_owners(n_global, n_ranks, owner);
+    return xpbd_halo_plan_owned(cell_keys, owner.data(), n_global, n_ranks, rank, joints, n_joints, ghosts, n_ghosts, boundary, n_boundary, nullptr, cap);
 }
 
 int xpbd_halo_plan_far(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, uint8_t *far, uint32_t cap, uint32_t *n_owned)
 {
     if (!cell_keys || !n_owned || n_ranks == 0 || n_ranks > 64 || rank >= n_ranks || (cap && !far))
         return set_error(XPBD_E_INVALID, "xpbd_halo_plan_far: bad argument");
+    std::vector<uint8_t> owner;
+    range_owners(n_global, n_ranks, owner);
     HaloPlanner planner;
-    planner.n = n_global, planner.w = n_ranks, planner.keys = cell_keys;
-    std::vector<uint32_t> g, b;
+    planner.n = n_global, planner.w = n_ranks, planner.keys = cell_keys, planner.owner = owner.data();
+    std::vector<uint32_t> own, g, b;
     std::vector<uint8_t> f;
-    planner.plan_rank(rank, nullptr, 0, g, b, &f);
+    planner.plan_rank(rank, nullptr, 0, own, g, b, &f);
     *n_owned = (uint32_t)f.size();
     if (f.size() > cap)
         return set_error(XPBD_E_CAPACITY, "xpbd_halo_plan_far: %zu owned bodies, capacity %u", f.size(), cap);

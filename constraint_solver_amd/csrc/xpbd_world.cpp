@@ -156,6 +156,19 @@ struct xpbd_world {
     DeviceBuffer cb_grid_partials, cb_items_unsorted;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
     bool have_neighbours = false;
+    // The broadphase in two halves (build_neighbours_enqueue / _collect): the counting kernels leave the totals the host
+    // needs to size the pair buffers in PINNED memory and record an event; only the second half waits for it.  A host that
+    // drives several worlds (xpbd_multi.cpp: one per GPU) enqueues all of them before it waits for any.
+    struct BroadphaseTotals {
+        uint32_t entries, pairs;
+        unsigned long long stats[2];
+    };
+    BroadphaseTotals *bp_totals = nullptr; // hipHostMalloc
+    hipEvent_t bp_event = nullptr;
+    bool bp_pending = false;
+    // state at the start of a frame (xpbd::frame_snapshot_save / _restore): the 13 dynamic fields and the contact masks
+    DeviceBuffer frame_snapshot;
+    bool frame_snapshot_valid = false, frame_snapshot_stepped = false;
     DeviceBuffer jt_joints, jt_off, jt_list;
     uint32_t n_joints = 0;
     // state history (xpbd_world_history_*): `history_length` slots of history_slot_bytes() in one growing block
@@ -250,9 +263,15 @@ int ensure_gjk_scratch(xpbd_world *w, uint32_t n_pairs)
     return XPBD_OK;
 }
 
-// Sphere broadphase of the contact pipeline: neighbour lists + pair list for the coming frame.
-int build_neighbours(xpbd_world *w, double dt)
+// Sphere broadphase of the contact pipeline: neighbour lists + pair list for the coming frame, in two halves.
+// First half: bounding spheres, buckets and the neighbour COUNT of every body are enqueued, the totals travel to pinned host
+// memory behind them, an event marks their arrival.  Nothing here waits for the device.
+int build_neighbours_enqueue(xpbd_world *w, double dt)
 {
+    if (!w->bp_totals) {
+        XPBD_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&w->bp_totals), sizeof *w->bp_totals, hipHostMallocDefault));
+        XPBD_HIP_TRY(hipEventCreateWithFlags(&w->bp_event, hipEventDisableTiming));
+    }
     const uint32_t n = w->n, st = w->stride;
     w->table_size = next_pow2(n < 512 ? 1024 : 2 * n);
     XPBD_HIP_TRY(w->cb_centers.reserve((size_t)3 * st * 8));
@@ -302,14 +321,28 @@ int build_neighbours(xpbd_world *w, double dt)
                                                w->stream));
     XPBD_HIP_TRY(xpbd::launch_build_buckets(b, c, w->stream));
     XPBD_HIP_TRY(xpbd::launch_neighbour_count(b, c, w->stream));
-    uint32_t totals[2] = {0, 0};
-    unsigned long long stats_now[2] = {0, 0};
-    XPBD_HIP_TRY(hipMemcpyAsync(&totals[0], c.nbr_off + n, 4, hipMemcpyDeviceToHost, w->stream));
-    XPBD_HIP_TRY(hipMemcpyAsync(&totals[1], c.pair_first + n, 4, hipMemcpyDeviceToHost, w->stream));
-    XPBD_HIP_TRY(hipMemcpyAsync(stats_now, c.stats, 16, hipMemcpyDeviceToHost, w->stream));
-    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
-    w->n_entries = totals[0];
-    w->n_pairs = totals[1];
+    XPBD_HIP_TRY(hipMemcpyAsync(&w->bp_totals->entries, c.nbr_off + n, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(&w->bp_totals->pairs, c.pair_first + n, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->bp_totals->stats, c.stats, 16, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipEventRecord(w->bp_event, w->stream));
+    w->bp_pending = true;
+    w->have_neighbours = false;
+    return XPBD_OK;
+}
+
+// Second half: waits for the totals (the one host synchronisation of a frame in XPBD_MODE_CONTACTS), sizes the pair
+// buffers and fills the neighbour and pair lists.
+int build_neighbours_collect(xpbd_world *w)
+{
+    if (!w->bp_pending)
+        return fail(XPBD_E_INVALID, "build_neighbours_collect without build_neighbours_enqueue");
+    XPBD_HIP_TRY(hipEventSynchronize(w->bp_event));
+    w->bp_pending = false;
+    const xpbd::BodyArrays b = w->arrays();
+    xpbd::ContactBuffers c = w->contact_buffers();
+    const unsigned long long stats_now[2] = {w->bp_totals->stats[0], w->bp_totals->stats[1]};
+    w->n_entries = w->bp_totals->entries;
+    w->n_pairs = w->bp_totals->pairs;
     {
         // Pre-test as a pass of its own for the coming frame?  Either way the results are the same bits; this only
         // picks the cheaper schedule from how many of the pairs examined since the last broadphase were touching.
@@ -353,6 +386,13 @@ int build_neighbours(xpbd_world *w, double dt)
     XPBD_HIP_TRY(xpbd::launch_neighbour_fill(b, c, w->stream));
     w->have_neighbours = true;
     return XPBD_OK;
+}
+
+int build_neighbours(xpbd_world *w, double dt)
+{
+    if (int rc = build_neighbours_enqueue(w, dt))
+        return rc;
+    return build_neighbours_collect(w);
 }
 
 // Narrowphase of the current substep on the post-integrate frames of `c`.
@@ -424,7 +464,7 @@ int step_contacts(xpbd_world *w, double dt, double h, uint32_t substeps, uint32_
 // ---- the frame of a multi-GPU shard, split at the halo exchange (xpbd_internal.h) -------------------------------------------
 namespace xpbd {
 
-int halo_frame_begin(xpbd_world *w, double dt, double h)
+int halo_frame_begin_enqueue(xpbd_world *w, double dt)
 {
     if (!w || w->mode != XPBD_MODE_CONTACTS || !w->has_topology)
         return fail(XPBD_E_INVALID, "halo_frame_begin: needs XPBD_MODE_CONTACTS and xpbd_world_set_polytopes");
@@ -432,10 +472,72 @@ int halo_frame_begin(xpbd_world *w, double dt, double h)
         return XPBD_OK;
     if (int rc = bind_device(w))
         return rc;
-    if (int rc = build_neighbours(w, dt))
+    return build_neighbours_enqueue(w, dt);
+}
+
+int halo_frame_begin_collect(xpbd_world *w, double h)
+{
+    if (!w || w->mode != XPBD_MODE_CONTACTS || !w->has_topology)
+        return fail(XPBD_E_INVALID, "halo_frame_begin: needs XPBD_MODE_CONTACTS and xpbd_world_set_polytopes");
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    if (int rc = build_neighbours_collect(w))
         return rc;
     XPBD_HIP_TRY(launch_integrate_ground(w->arrays(), w->shapes(), h, w->contact_buffers(0), w->last_mask.as<uint32_t>(), nullptr, 0, w->stream));
     w->stepped = true;
+    return XPBD_OK;
+}
+
+int halo_frame_begin(xpbd_world *w, double dt, double h)
+{
+    if (int rc = halo_frame_begin_enqueue(w, dt))
+        return rc;
+    return halo_frame_begin_collect(w, h);
+}
+
+// The state a frame starts from -- the 13 dynamic fields of every body and the contact masks of the last substep -- kept
+// aside (device to device, on the world's stream) so that a frame whose halos turn out to have been too thin can be undone.
+int frame_snapshot_save(xpbd_world *w)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "frame_snapshot_save: NULL world");
+    if (w->n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    const size_t dyn_bytes = (size_t)kDynFields * w->stride * 8, mask_bytes = (size_t)w->stride * 4;
+    if (w->frame_snapshot.bytes < dyn_bytes + mask_bytes) {
+        XPBD_HIP_TRY(hipStreamSynchronize(w->stream)); // reserve() frees the old block
+        XPBD_HIP_TRY(w->frame_snapshot.reserve(dyn_bytes + mask_bytes));
+    }
+    char *dst = static_cast<char *>(w->frame_snapshot.ptr);
+    XPBD_HIP_TRY(hipMemcpyAsync(dst, w->dyn.ptr, dyn_bytes, hipMemcpyDeviceToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(dst + dyn_bytes, w->last_mask.ptr, mask_bytes, hipMemcpyDeviceToDevice, w->stream));
+    w->frame_snapshot_valid = true;
+    w->frame_snapshot_stepped = w->stepped;
+    return XPBD_OK;
+}
+
+int frame_snapshot_restore(xpbd_world *w)
+{
+    if (!w)
+        return fail(XPBD_E_INVALID, "frame_snapshot_restore: NULL world");
+    if (w->n == 0)
+        return XPBD_OK;
+    if (!w->frame_snapshot_valid)
+        return fail(XPBD_E_INVALID, "frame_snapshot_restore: no snapshot");
+    if (int rc = bind_device(w))
+        return rc;
+    const size_t dyn_bytes = (size_t)kDynFields * w->stride * 8, mask_bytes = (size_t)w->stride * 4;
+    const char *src = static_cast<const char *>(w->frame_snapshot.ptr);
+    XPBD_HIP_TRY(hipMemcpyAsync(w->dyn.ptr, src, dyn_bytes, hipMemcpyDeviceToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->last_mask.ptr, src + dyn_bytes, mask_bytes, hipMemcpyDeviceToDevice, w->stream));
+    w->stepped = w->frame_snapshot_stepped;
+    w->have_neighbours = false;
+    w->bp_pending = false;
+    w->trace_rows = 0;
     return XPBD_OK;
 }
 
@@ -598,6 +700,11 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_stat_shape, &w->cb_pair_codes, &w->cb_rec_b,
                             &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
+    w->frame_snapshot.release();
+    if (w->bp_totals)
+        (void)hipHostFree(w->bp_totals);
+    if (w->bp_event)
+        (void)hipEventDestroy(w->bp_event);
     if (w->own_stream)
         (void)hipStreamDestroy(w->own_stream);
     delete w;
@@ -878,6 +985,8 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     }
     w->stepped = false;
     w->trace_rows = 0;
+    w->frame_snapshot_valid = false;
+    w->bp_pending = false;
     if (n == 0)
         return XPBD_OK;
     XPBD_HIP_TRY(hipMemcpyAsync(w->aos_staging.ptr, aos, (size_t)n * sizeof(xpbd_rigid), hipMemcpyHostToDevice,

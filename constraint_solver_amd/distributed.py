@@ -7,10 +7,13 @@ with tests/halo_common.OracleBackend standing in for the device) and tests/test_
 
 Scheme
 ------
-* Ownership: contiguous index ranges (sharding.shard_range), as for the pinned path -- of the caller's
-  body order (order="index") or of the bodies sorted by spatial-hash cell (order="spatial": x-major
-  cell order, so every rank owns a slab of space and the halos are thin).  The spatial order is a
-  renumbering: results equal a single-device run over the same renumbered bodies, bit for bit.
+* Ownership: order="library" (what the native world does, csrc/xpbd_multi.cpp): the x-major sequence of
+  spatial-hash cells is cut into world_size runs of near-equal body count (partition_owner), so every rank
+  owns a slab of space whatever the caller's numbering, and a re-plan re-balances the slabs; bodies keep
+  the caller's numbering and results equal a single-device run over the caller's bodies, bit for bit.
+  Older forms, kept: contiguous index ranges (sharding.shard_range) of the caller's body order
+  (order="index") or of the bodies renumbered by cell (order="spatial": results equal a single-device
+  run over the renumbered bodies).
 * Every rank's world holds OWNED bodies plus GHOST copies of remote bodies that can reach an
   owned body before the next re-plan; the local order is ascending global id, so every
   neighbour list and every floating-point sum has the same order as on a single device.
@@ -58,6 +61,47 @@ def spatial_order(bodies, shape_id, shape_radius, shape_centroid, pad, halo_marg
     return np.lexsort((np.arange(len(bodies)), cell[:, 2], cell[:, 1], cell[:, 0]))
 
 
+def cell_keys(centre, edge):
+    """Spatial-hash cell key of every centre (x-major: ascending keys are slabs along x), as xpbd_halo_cell_key."""
+    lim = (1 << 20) - 4
+    cell = np.clip(np.nan_to_num(np.floor(np.asarray(centre) / edge), nan=-lim, posinf=lim, neginf=-lim), -lim, lim).astype(np.int64)
+    return HaloPlan._key(cell)
+
+
+def partition_owner(key, world_size):
+    """owner[g] from the cell keys of ALL bodies, as xpbd_halo_partition (csrc/xpbd_multi.cpp partition_cuts): the bodies
+    sorted by (key, index) are cut into world_size runs at the positions of sharding.shard_range, each cut moved to the
+    nearer boundary of the cell it falls into -- unless that leaves more than a quarter of a share on the wrong side, in
+    which case the cell is split by body index."""
+    key = np.asarray(key, dtype=np.int64)
+    n = len(key)
+    owner = np.zeros(n, dtype=np.uint8)
+    if n == 0 or world_size < 2:
+        return owner
+    order = np.lexsort((np.arange(n), key))
+    sk = key[order]
+    share = max(1, n // world_size)
+    big = (np.iinfo(np.int64).max, 2 ** 32 - 1)
+    cuts = [(np.iinfo(np.int64).min, 0)]
+    for r in range(1, world_size):
+        t = shard_range(n, r, world_size)[0]
+        if t >= n:
+            cut = big
+        else:
+            K = int(sk[t])
+            less, leq = int(np.searchsorted(sk, K, "left")), int(np.searchsorted(sk, K, "right"))
+            before, after = t - less, leq - t
+            if min(before, after) * 4 <= share:
+                cut = (K, 0) if before <= after else (K + 1, 0)
+            else:
+                cut = (K, int(order[t]))
+        cuts.append(max(cut, cuts[-1]))
+    pairs = list(zip(key.tolist(), range(n)))
+    for g, pair in enumerate(pairs):
+        owner[g] = sum(1 for c in cuts if c <= pair) - 1
+    return owner
+
+
 class HaloMarginExceeded(RuntimeError):
     """A body travelled farther than halo_margin since the halos were planned: remote contacts may have been missed."""
 
@@ -66,20 +110,28 @@ class HaloPlan:
     """Which remote bodies each rank mirrors, and where they sit in the all-gather buffer.
     Deterministic function of the global sphere table, so every rank computes the same plan."""
 
-    def __init__(self, centre, radius, world_size, halo_margin, pad, joint_pairs=None):
+    def __init__(self, centre, radius, world_size, halo_margin, pad, joint_pairs=None, owner=None):
+        """owner: None = contiguous index ranges; "library" = partition_owner of the cell keys; or an array."""
         n = centre.shape[0]
         self.n, self.world_size = n, world_size
         edge = 2.0 * (float(radius.max()) + pad + halo_margin) if n else 1.0
         cell = np.floor(centre / edge).astype(np.int64)
         key = self._key(cell)
-        self.owned = [shard_range(n, r, world_size) for r in range(world_size)]
-        owner = np.zeros(n, dtype=np.int64)
-        for r, (first, count) in enumerate(self.owned):
-            owner[first:first + count] = r
+        if owner is None:
+            owner = np.zeros(n, dtype=np.int64)
+            for r in range(world_size):
+                first, count = shard_range(n, r, world_size)
+                owner[first:first + count] = r
+        elif isinstance(owner, str):
+            owner = partition_owner(key, world_size).astype(np.int64)
+        else:
+            owner = np.asarray(owner, dtype=np.int64)
+        self.own_ids = [np.nonzero(owner == r)[0] for r in range(world_size)]
+        self.owned = [(int(ids[0]) if len(ids) else 0, len(ids)) for ids in self.own_ids]   # (first, count): ranges when owner is None
         offsets = np.array([(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=np.int64)
         self.local_ids, ghost_sets = [], []
-        for r, (first, count) in enumerate(self.owned):
-            own_cells = np.unique(cell[first:first + count], axis=0)
+        for r, own in enumerate(self.own_ids):
+            own_cells = np.unique(cell[own], axis=0) if len(own) else np.zeros((0, 3), dtype=np.int64)
             reach = np.unique(self._key((own_cells[:, None, :] + offsets[None, :, :]).reshape(-1, 3)))
             remote = np.nonzero((owner != r) & np.isin(key, reach))[0]
             if joint_pairs is not None and len(joint_pairs):
@@ -88,12 +140,12 @@ class HaloPlan:
                 partners = np.concatenate([b[(owner[a] == r) & (owner[b] != r)], a[(owner[b] == r) & (owner[a] != r)]])
                 remote = np.union1d(remote, partners)
             ghost_sets.append(remote)
-            self.local_ids.append(np.sort(np.concatenate([np.arange(first, first + count), remote])))
+            self.local_ids.append(np.sort(np.concatenate([own, remote])))
         needed = np.zeros(n, dtype=bool)
         for g in ghost_sets:
             needed[g] = True
         # boundary bodies of each rank = its owned bodies that some other rank mirrors, ascending
-        self.boundary = [np.nonzero(needed[f:f + c])[0] + f for (f, c) in self.owned]
+        self.boundary = [own[needed[own]] for own in self.own_ids]
         self.capacity = max([len(b) for b in self.boundary] + [1])
         self.ghosts = ghost_sets
         self._owner = owner
@@ -107,8 +159,7 @@ class HaloPlan:
         """Index arrays of one rank: local ids (global id per local slot), owned mask, local slots of its
         boundary bodies, local slots of its ghosts and their rows in the gathered [W * capacity] buffer."""
         ids = self.local_ids[rank]
-        first, count = self.owned[rank]
-        owned_mask = (ids >= first) & (ids < first + count)
+        owned_mask = self._owner[ids] == rank
         boundary_slots = np.searchsorted(ids, self.boundary[rank])
         ghost_ids = self.ghosts[rank]
         ghost_slots = np.searchsorted(ids, ghost_ids)
@@ -179,6 +230,7 @@ class ShardedContactWorld:
         bodies_global = np.asarray(bodies_global, dtype=np.float64)
         shape_id_global = np.asarray(shape_id_global, dtype=np.uint32)
         # `perm[k]` = caller's index of the body that is number k internally
+        self.library_owner = order == "library"         # ownership by partition_owner, re-cut at every plan; no renumbering
         self.perm = spatial_order(bodies_global, shape_id_global, shape_radius, shape_centroid, pad, halo_margin) \
             if order == "spatial" else np.arange(bodies_global.shape[0])
         inverse = np.empty_like(self.perm)
@@ -195,7 +247,8 @@ class ShardedContactWorld:
         centre, radius = bounding_spheres(bodies_global, self.shape_id_global, self.shape_radius, self.shape_centroid)
         jg = self.joints_global
         pairs = None if jg is None or not len(jg) else np.stack([jg["body_a"], jg["body_b"]], axis=1).astype(np.int64)
-        self.plan = HaloPlan(centre, radius, self.world_size, self.halo_margin, self.pad, joint_pairs=pairs)
+        self.plan = HaloPlan(centre, radius, self.world_size, self.halo_margin, self.pad, joint_pairs=pairs,
+                             owner="library" if self.library_owner else None)
         ids, self.owned_mask, boundary_slots, ghost_slots, rows = self.plan.rank_view(self.rank)
         self.local_ids = ids
         b = self.backend
@@ -278,7 +331,7 @@ class ShardedContactWorld:
         ids, state = self.owned_state()
         if self.world_size == 1:
             return state
-        cap = max(c for _, c in self.plan.owned)
+        cap = max(len(own) for own in self.plan.own_ids)
         mine = torch.zeros(cap, 38, dtype=torch.float64)
         mine[: len(ids)] = torch.from_numpy(state)
         on_nccl = dist.get_backend(self.group) == "nccl"
@@ -286,7 +339,10 @@ class ShardedContactWorld:
             mine = mine.cuda()
         parts = [torch.zeros_like(mine) for _ in range(self.world_size)]
         dist.all_gather(parts, mine, group=self.group)
-        return np.concatenate([parts[r][: self.plan.owned[r][1]].cpu().numpy() for r in range(self.world_size)])
+        out = np.empty((self.plan.n, 38))
+        for r, own in enumerate(self.plan.own_ids):          # every rank knows every rank's owned ids: the plan is global
+            out[own] = parts[r][: len(own)].cpu().numpy()
+        return out
 
     def gather_global_in_caller_order(self):
         """gather_global() mapped back from the internal (possibly spatial) numbering to the caller's body order."""
@@ -297,5 +353,5 @@ class ShardedContactWorld:
 
     def replan(self):
         """Re-select the halos from the current positions (call before any body has moved halo_margin).
-        The numbering (and with it the ownership) is kept; only the ghost sets change."""
+        The numbering is kept; with order="library" the shards are re-cut (re-balanced) as well, else only the ghost sets change."""
         self._plan(self.gather_global())

@@ -199,9 +199,16 @@ extern "C" {
     pub fn xpbd_multi_world_replan(mw: *mut XpbdMultiWorld) -> c_int;
     pub fn xpbd_multi_world_synchronize(mw: *mut XpbdMultiWorld) -> c_int;
     pub fn xpbd_multi_world_download(mw: *mut XpbdMultiWorld, out: *mut XpbdRigid, n: u32) -> c_int;
+    pub fn xpbd_multi_world_download_owned(mw: *mut XpbdMultiWorld, ids: *mut u32, out: *mut XpbdRigid, cap: u32, n_out: *mut u32) -> c_int;
     pub fn xpbd_multi_world_halo_stats(mw: *mut XpbdMultiWorld, out: *mut u64, max_displacement: *mut f64) -> c_int;
+    pub fn xpbd_multi_world_plan_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int;
+    pub fn xpbd_multi_world_owners(mw: *mut XpbdMultiWorld, owner: *mut u8, n_global: u32) -> c_int;
     pub fn xpbd_multi_world_contact_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int;
     pub fn xpbd_halo_cell_key(centre: *const f64, cell_edge: f64) -> i64;
+    pub fn xpbd_halo_partition(cell_keys: *const i64, n_global: u32, n_ranks: u32, owner: *mut u8) -> c_int;
+    pub fn xpbd_halo_plan_owned(cell_keys: *const i64, owner: *const u8, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint,
+                                n_joints: u32, ghosts: *mut u32, n_ghosts: *mut u32, boundary: *mut u32, n_boundary: *mut u32, far: *mut u8,
+                                cap: u32) -> c_int;
     pub fn xpbd_halo_plan_far(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, far: *mut u8, cap: u32, n_owned: *mut u32) -> c_int;
     pub fn xpbd_halo_plan(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint, n_joints: u32,
                           ghosts: *mut u32, n_ghosts: *mut u32, boundary: *mut u32, n_boundary: *mut u32, cap: u32) -> c_int;

@@ -23,7 +23,9 @@
  *
  * Threading: one xpbd_world is used from one thread at a time; distinct worlds
  * are independent.  step() enqueues on the world's HIP stream and returns;
- * download_* and synchronize() wait.  No call throws or unwinds across the ABI.
+ * download_* and synchronize() wait (XPBD_MODE_CONTACTS: step() waits ONCE, for the
+ * broadphase's pair counts, which size the pair buffers; everything after that is
+ * enqueued).  No call throws or unwinds across the ABI.
  */
 #ifndef XPBD_H
 #define XPBD_H
@@ -35,7 +37,8 @@
 extern "C" {
 #endif
 
-#define XPBD_ABI_VERSION 1u
+/* 2: xpbd_multi_world_* (library-owned sharding), XPBD_E_HALO, edge_axes_separation, state history */
+#define XPBD_ABI_VERSION 2u
 
 /* Error codes (reference has no Result on this path; it panics). */
 #define XPBD_OK                   0
@@ -299,17 +302,35 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
 
 /* ---------------------------------------------------------------------------
  * Multi-GPU world (EXTENSION): the caller is still World::integrate (src/world.rs:34-43), now over an N-body
- * world in XPBD_MODE_CONTACTS whose bodies are sharded over the GPUs of one node by contiguous global index range -- order
- * the bodies so that index ranges are compact in space (grid rows, spatial-hash cell order) and the halos are thin.
+ * world in XPBD_MODE_CONTACTS whose bodies are sharded over the GPUs of one node.  The caller numbers its bodies as it likes:
+ * OWNERSHIP IS THE LIBRARY'S.  At every plan the bodies are binned into a uniform grid (cell edge = 2 * (largest bounding
+ * radius + contact_pad + halo_margin)), the cells are ordered by spatial-hash cell key (x-major) and that sequence is cut
+ * into n_ranks runs of near-equal body count: every rank owns a slab of space; a re-plan re-balances the slabs (bodies
+ * change owner as a pile migrates).  Bodies keep the caller's numbering everywhere in this interface.
  * One xpbd_multi_world drives this process's LOCAL shards of the n_ranks shards of the world: all of them (one process owns
  * every GPU) or one each (one process per GPU).  Every shard steps its owned bodies plus ghost copies of the remote
  * bodies within reach, and after EVERY substep the boundary bodies' 13 dynamic doubles travel in ONE all-gather (RCCL over
  * xGMI; XPBD_TRANSPORT_LOCAL = peer copies inside one process, also the single-GPU rehearsal with several shards on one
- * device).  The library builds the halo plan itself (no rank holds the global scene) and checks once per frame, over all
- * ranks, how much of its travel allowance any body has used since (halo_margin next to a shard boundary, halo_margin + half
- * a cell edge for a body more than two cells away from every foreign one): beyond it the step FAILS with XPBD_E_HALO rather
- * than lose remote contacts silently; XPBD_MULTI_AUTO_REPLAN re-plans at half the allowance.  Result: bit-identical to one xpbd_world over
- * the same bodies in the same order.
+ * device).  The library builds the halo plan itself (no rank holds the global scene) and checks at the END of every frame,
+ * over all ranks, how much of its travel allowance any body has used since the plan (halo_margin next to a shard boundary,
+ * halo_margin + half a cell edge for a body more than two cells away from every foreign one).  Beyond it a remote contact
+ * may have been missed in that frame, so the frame is UNDONE (the state it started from is kept aside on the device) and
+ * either run again after a re-plan (XPBD_MULTI_AUTO_REPLAN, which also re-plans pre-emptively at half the allowance) or
+ * reported as XPBD_E_HALO with the frame's start state in place.  Result: bit-identical to one xpbd_world over the same bodies
+ * in the same order -- a state with possibly missed contacts never reaches the caller.
+ *
+ * Collective calls (create, upload, step, replan, download) must be made by every rank in the same order.  Failure model: a
+ * rank that fails LOCALLY inside upload / replan / step / download (out of memory, a launch error) still takes part in the
+ * call's collectives, each of which carries every rank's status, so EVERY rank returns an error from that call (the failing
+ * rank its own, the others the same code with a message naming the rank) and a failed frame is undone everywhere.  If a
+ * collective itself cannot be enqueued the communicator is aborted (ncclCommAbort: blocked peers return with an error) and
+ * every later call on that world fails: destroy it.  Argument errors are returned before any collective: the ranks' hosts
+ * pass consistent arguments.  A rank that never reaches xpbd_multi_world_create leaves its peers waiting inside RCCL's
+ * bootstrap; only the host's launcher can detect that.
+ * Threading: xpbd_multi_world_step waits once for the broadphase's pair counts (all shards' broadphases are enqueued before
+ * the first wait) and, with n_ranks > 1, for the end of the frame (the validity check).
+ * The RCCL transport has run on hardware with a ONE-rank communicator only (the build box has one GPU and RCCL refuses two
+ * ranks on one device); everything else is verified with XPBD_TRANSPORT_LOCAL.
  * ------------------------------------------------------------------------- */
 #define XPBD_COMM_ID_BYTES 128u         /* sizeof(ncclUniqueId) */
 #define XPBD_TRANSPORT_RCCL  0u
@@ -344,27 +365,49 @@ void xpbd_multi_config_default(xpbd_multi_config *cfg);
 int  xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg);   /* collective over all ranks (RCCL) */
 void xpbd_multi_world_destroy(xpbd_multi_world *mw);
 int  xpbd_multi_world_set_polytopes(xpbd_multi_world *mw, const xpbd_polytope *shapes, uint32_t n_shapes);
-/* bodies: the bodies this process's shards own = global indices [first_global, first_global + n_bodies) of n_global (rank r
- * owns the r-th of n_ranks near-equal contiguous ranges, the first n_global % n_ranks one body longer); joints: ALL joints of
- * the world with GLOBAL body indices, the same list on every rank.  Collective: builds the halo plan. */
+/* bodies: the slice of the caller's bodies this process HANDS OVER = global indices [first_global, first_global + n_bodies) of
+ * n_global (rank r hands over the r-th of n_ranks near-equal contiguous ranges, the first n_global % n_ranks one body longer;
+ * any order -- which rank ends up owning a body is decided by where the body is); joints: ALL joints of the world with GLOBAL
+ * body indices, the same list on every rank.  A non-finite position is XPBD_E_INVALID (the body cannot be placed in the
+ * grid).  Collective: cuts the shards, moves every body to its owner and builds the halo plan. */
 int  xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, const uint32_t *shape_id, uint32_t first_global,
                              uint32_t n_bodies, uint32_t n_global, const xpbd_joint *joints, uint32_t n_joints);
-/* xpbd_world_step(dt, substeps) of the whole sharded world; collective, asynchronous after the broadphase. */
+/* xpbd_world_step(dt, substeps) of the whole sharded world; collective.  XPBD_E_HALO: see above (the frame was undone). */
 int  xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps);
-int  xpbd_multi_world_replan(xpbd_multi_world *mw);                                     /* collective; clears XPBD_E_HALO */
+/* Re-cuts the shards from the bodies' current positions (re-balancing them), migrates bodies whose owner changed and
+ * re-plans the halos.  Collective; clears XPBD_E_HALO. */
+int  xpbd_multi_world_replan(xpbd_multi_world *mw);
 int  xpbd_multi_world_synchronize(xpbd_multi_world *mw);
-int  xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n);     /* the owned bodies, global order */
+/* The slice this process handed over, [first_global, first_global + n), in the caller's order.  Collective (with more than
+ * one process every owner's bodies travel in one all-gather: use download_owned on large worlds). */
+int  xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n);
+/* The bodies this process's shards OWN at the moment, with their global indices (ids[k] belongs to out[k]); *n_out receives
+ * their number even when it exceeds cap (then XPBD_E_CAPACITY).  Not collective. */
+int  xpbd_multi_world_download_owned(xpbd_multi_world *mw, uint32_t *ids, xpbd_rigid *out, uint32_t cap, uint32_t *n_out);
 /* out = {bodies of the world, owned here, ghosts here, boundary bodies here, rows per rank of the all-gather, plans made};
  * *max_displacement (optional) = the largest fraction of its travel allowance any body had used at the last check, in
  * margin-equivalent metres (x halo_margin). */
 int  xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *max_displacement);
+/* out = {plans made, frames undone (halo violations), bodies that changed owner at the last plan, fewest / most bodies owned
+ * by a rank, step calls, and the host time inside them in ns: enqueueing, waiting for the broadphases' pair counts, waiting
+ * for the end of the frame; 0}. */
+int  xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10]);
+/* owner[g] = rank that owns body g as of the last plan (n_global entries). */
+int  xpbd_multi_world_owners(xpbd_multi_world *mw, uint8_t *owner, uint32_t n_global);
 int  xpbd_multi_world_contact_stats(xpbd_multi_world *mw, uint64_t out[3]);             /* sums of xpbd_world_contact_stats */
-/* Diagnostics, host only (no device needed): the grid cell key of a bounding-sphere centre, and one rank's halo plan from
- * the cell keys of all bodies (ascending ghost ids: the remote bodies it mirrors; ascending boundary ids: its own bodies
- * that others mirror) exactly as xpbd_multi_world_upload computes it. */
+/* Diagnostics, host only (no device needed), exactly as the plans compute them.  The grid cell key of a bounding-sphere
+ * centre (x-major: ascending keys are slabs along x); the owner of every body from the cell keys of all bodies (the key
+ * sequence cut into n_ranks runs of near-equal body count, on cell boundaries unless a rank would end up more than a quarter
+ * of its share off balance -- then the cell is split by body index); and one rank's halo plan from keys and owners (ascending
+ * ghost ids: the remote bodies it mirrors; ascending boundary ids: its own bodies that others mirror; far (optional): per
+ * owned body in ascending index, 1 if no foreign body lies within two cells, so that it may travel halo_margin + half a cell
+ * edge before the halos must be re-planned, the others halo_margin). */
 int64_t xpbd_halo_cell_key(const double centre[3], double cell_edge);
-/* ... and which of the rank's own bodies (in index order) the plan classes as FAR: no foreign body within two cells, so
- * they may travel halo_margin + half a cell edge before the halos must be re-planned (the others halo_margin). */
+int  xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint8_t *owner);
+int  xpbd_halo_plan_owned(const int64_t *cell_keys, const uint8_t *owner, uint32_t n_global, uint32_t n_ranks, uint32_t rank,
+                          const xpbd_joint *joints, uint32_t n_joints, uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary,
+                          uint32_t *n_boundary, uint8_t *far, uint32_t cap);
+/* ... the same with ownership by contiguous index ranges (rank r owns the r-th of n_ranks near-equal ranges). */
 int  xpbd_halo_plan_far(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, uint8_t *far, uint32_t cap,
                         uint32_t *n_owned);
 int  xpbd_halo_plan(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, const xpbd_joint *joints,

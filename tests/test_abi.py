@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(os.path.join(capi.LIB_DIR, "libxpbd_hip.so"))
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.xpbd_abi_version() == 1
+    assert lib.xpbd_abi_version() == 2
 
 
 def test_rust_binding_text_declares_every_symbol():

@@ -1,8 +1,10 @@
 """The native multi-GPU world (xpbd_multi_world_*, csrc/xpbd_multi.cpp) on the one GPU of the box: several shards on
 device 0 with the in-process transport (XPBD_TRANSPORT_LOCAL) must reproduce a single xpbd_world over the same bodies BIT FOR
-BIT -- halo plan built by the library, one all-gather per substep, joints crossing shard boundaries, re-plans -- and the
-oracle; a body that outruns halo_margin must be an error (XPBD_E_HALO), not a silently lost contact; the RCCL transport is
-exercised with a one-rank communicator (RCCL refuses two ranks on one device).  EXTENSION: parity unpinned."""
+BIT -- shards cut by the library from the spatial-hash cell order whatever the caller's numbering, halo plan built by the
+library, one all-gather per substep, joints crossing shard boundaries, re-plans that re-balance -- and the oracle; a frame in
+which a body outruns halo_margin is UNDONE and reported (XPBD_E_HALO) or re-run after a re-plan, never a silently lost
+contact; the RCCL transport is exercised with a one-rank communicator (RCCL refuses two ranks on one device).
+EXTENSION: parity unpinned."""
 import numpy as np
 import pytest
 
@@ -89,28 +91,122 @@ def test_sharded_pile_with_joints_across_shards_and_gjk():
         assert bits_equal(got, one)
 
 
-def test_a_body_that_outruns_the_halo_margin_is_an_error_not_a_lost_contact():
-    kind, n, substeps = capi.SCENE_BOXES_DROP, 64, 4
+def boundary_body(kind, bodies, sid, n_ranks, margin):
+    """Index of a body the plan puts next to a shard boundary (travel allowance = halo_margin, not the larger one of a
+    body deep inside its slab)."""
+    with capi.MultiWorld(n_ranks, devices=[0] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=margin) as mw:
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.upload(bodies, sid, 0, len(bodies))
+        owner = mw.owners()
+    x = bodies[:, 31]
+    edge_x = 0.5 * (x[owner == 0].max() + x[owner == 1].min())
+    return int(np.argmin(np.abs(x - edge_x) + 1e3 * (owner != 0)))
+
+
+def test_a_frame_in_which_a_body_outruns_the_halo_margin_is_undone_and_reported():
+    """The validity check sits at the END of the frame: the frame that used up the allowance returns XPBD_E_HALO with the
+    state of its START in place, so no state with possibly missed contacts ever reaches the caller; after a re-plan the
+    same frame goes through and the run equals the single device."""
+    kind, n, substeps, margin = capi.SCENE_BOXES_DROP, 64, 4, 0.5
     bodies, sid = line_scene(capi, kind, n, 3, 1.5)
-    bodies[5, 22:25] = [0.0, 0.0, 40.0]                                  # 40 m/s upwards: 0.67 m per frame against a 0.5 m margin
-    with capi.MultiWorld(2, devices=[0, 0], transport=capi.TRANSPORT_LOCAL, halo_margin=0.5) as mw:
+    fast = boundary_body(kind, bodies, sid, 2, margin)
+    bodies[fast, 22:25] = [0.0, 0.0, 20.0]                               # 20 m/s upwards: 0.33 m per frame against a 0.5 m margin
+    with capi.MultiWorld(2, devices=[0, 0], transport=capi.TRANSPORT_LOCAL, halo_margin=margin) as mw:
         mw.set_polytopes(capi.scene_polytopes(kind))
         mw.upload(bodies, sid, 0, n)
-        mw.step(DT, substeps)                                            # nothing has moved yet when this frame is checked
-        with pytest.raises(capi.XpbdError) as e:
+        mw.step(DT, substeps)                                            # 0.33 m: within the margin
+        after_one = mw.download()
+        with pytest.raises(capi.XpbdError) as e:                         # 0.66 m since the plan: this frame is undone
             mw.step(DT, substeps)
-        assert e.value.code == capi.E_HALO and "halo_margin" in str(e.value)
-        assert mw.halo_stats()["max_displacement"] > 0.5
+        assert e.value.code == capi.E_HALO and "halo_margin" in str(e.value) and "undone" in str(e.value)
+        assert mw.halo_stats()["max_displacement"] > margin and mw.plan_stats()["rollbacks"] == 1
         with pytest.raises(capi.XpbdError) as e:                         # sticky until the halos are re-planned
             mw.step(DT, substeps)
         assert e.value.code == capi.E_HALO
+        assert bits_equal(mw.download(), after_one)                      # the state of the failed frame's start
         mw.replan()
+        mw.step(DT, substeps)                                            # the same frame again, from a fresh plan
+        mw.replan()                                                      # (0.33 m per frame: a plan holds for one frame)
         mw.step(DT, substeps)
-    # with automatic re-planning and a margin that holds for one frame the same scene runs, and equals the single device
+        got = mw.download()
+    one, _ = single(bodies, sid, kind, 3, substeps)
+    assert bits_equal(got, one)
+    assert bits_equal(after_one, single(bodies, sid, kind, 1, substeps)[0])
+    # a body that leaves the margin within ONE frame cannot be stepped at all with this margin: error, state untouched
+    bodies[fast, 22:25] = [0.0, 0.0, 40.0]                               # 0.67 m per frame
+    for auto in (False, True):
+        with capi.MultiWorld(2, devices=[0, 0], transport=capi.TRANSPORT_LOCAL, halo_margin=margin, auto_replan=auto) as mw:
+            mw.set_polytopes(capi.scene_polytopes(kind))
+            mw.upload(bodies, sid, 0, n)
+            with pytest.raises(capi.XpbdError) as e:
+                mw.step(DT, substeps)
+            assert e.value.code == capi.E_HALO
+            assert bits_equal(mw.download(), bodies)
+    # with a margin that holds for one frame and automatic re-planning the same scene runs, and equals the single device
     got, _, s1, _ = sharded(bodies, sid, kind, 2, 12, substeps, margin=1.5, auto_replan=True)
     assert s1["plans"] > 2
     one, _ = single(bodies, sid, kind, 12, substeps)
     assert bits_equal(got, one)
+
+
+def test_automatic_replanning_undoes_and_reruns_a_frame_that_outran_its_halos():
+    """A body that accelerates: 0.2 m in the first frame (no pre-emptive re-plan yet: that comes at half the margin), 0.4 m
+    more in the second -- 0.6 m since the plan, beyond the 0.5 m margin.  With XPBD_MULTI_AUTO_REPLAN the second frame is
+    undone, the halos are re-planned from its start state and the frame runs again: the caller sees nothing but the
+    single-device result."""
+    kind, n, substeps, margin = capi.SCENE_BOXES_DROP, 64, 4, 0.5
+    bodies, sid = line_scene(capi, kind, n, 3, 1.5)
+    fast = boundary_body(kind, bodies, sid, 2, margin)
+    bodies[fast, 22:25] = [0.0, 0.0, 6.0]
+    bodies[fast, 10:13] = [0.0, 0.0, 720.0 / bodies[fast, 0]]           # 720 m/s^2 upwards: +12 m/s per frame
+    with capi.MultiWorld(2, devices=[0, 0], transport=capi.TRANSPORT_LOCAL, halo_margin=margin, auto_replan=True) as mw:
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.upload(bodies, sid, 0, n)
+        mw.step(DT, substeps)
+        assert mw.plan_stats()["rollbacks"] == 0 and mw.halo_stats()["plans"] == 1
+        mw.step(DT, substeps)
+        stats = mw.plan_stats()
+        assert stats["rollbacks"] == 1 and stats["plans"] >= 2
+        got = mw.download()
+    one, _ = single(bodies, sid, kind, 2, substeps)
+    assert bits_equal(got, one)
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_the_library_cuts_the_shards_whatever_the_callers_numbering(n_ranks):
+    """The same pile numbered at random and numbered row by row: both sharded runs equal the single device over the same
+    numbering, the shards are slabs of space in both (as few ghosts for the shuffled scene as for the ordered one) and
+    near-equal in size; the re-plans on the way re-balance them."""
+    kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 1200, 8, 30
+    bodies, sid = capi.scene_pile(kind, 5, n, 1.8, 3)
+    joints = chain_joints(capi, n, every=7)
+    centre = bodies[:, 31:34] + bodies[:, 28:31]
+    joints["distance"] = np.linalg.norm(centre[joints["body_b"]] - centre[joints["body_a"]], axis=1)
+    perm = np.random.default_rng(9).permutation(n)                       # caller's index k holds pile body perm[k]
+    inverse = np.empty_like(perm)
+    inverse[perm] = np.arange(n)
+    shuffled_joints = joints.copy()
+    shuffled_joints["body_a"], shuffled_joints["body_b"] = inverse[joints["body_a"]], inverse[joints["body_b"]]
+    results = {}
+    for name, (b, s, j) in {"ordered": (bodies, sid, joints), "shuffled": (bodies[perm], sid[perm], shuffled_joints)}.items():
+        with capi.MultiWorld(n_ranks, devices=[0] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=1.0, auto_replan=True) as mw:
+            mw.set_polytopes(capi.scene_polytopes(kind))
+            mw.upload(b, s, 0, n, j)
+            halo0, plan0, owner0 = mw.halo_stats(), mw.plan_stats(), mw.owners()
+            for _ in range(frames):
+                mw.step(DT, substeps)
+            got, plan1 = mw.download(), mw.plan_stats()
+            ids, owned = mw.download_owned()
+        one, one_stats = single(b, s, kind, frames, substeps, joints=j)
+        assert one_stats[1] > 100 and bits_equal(got, one)
+        assert np.array_equal(np.sort(ids), np.arange(n)) and bits_equal(owned, one[ids])
+        assert plan0["owned_max"] - plan0["owned_min"] <= n // n_ranks // 4 and plan1["owned_max"] - plan1["owned_min"] <= n // n_ranks // 4
+        assert plan1["plans"] > 1
+        results[name] = (halo0["ghosts"], owner0)
+    g_ordered, g_shuffled = results["ordered"][0], results["shuffled"][0]
+    assert 0 < g_shuffled <= 1.1 * g_ordered + 8                        # the caller's numbering does not thicken the halos
+    # the same body has the same owner under both numberings (up to the few bodies of a cell split between two ranks)
+    assert np.mean(results["shuffled"][1] == results["ordered"][1][perm]) > 0.97
 
 
 def test_rccl_transport_with_a_one_rank_communicator():
@@ -204,12 +300,12 @@ dist.destroy_process_group()
 
 def test_multi_world_edge_cases():
     """More ranks than bodies (empty shards), a one-body world, a world without any contact, re-uploading a different scene
-    into the same multi world, and NaN bodies (which count as having outrun every margin)."""
+    into the same multi world, and a NaN position (rejected at upload)."""
     kind = capi.SCENE_BOXES_DROP
     bodies, sid = line_scene(capi, kind, 3, 5, 1.3)
     with capi.MultiWorld(4, devices=[0] * 4, transport=capi.TRANSPORT_LOCAL, auto_replan=True) as mw:
         mw.set_polytopes(capi.scene_polytopes(kind))
-        mw.upload(bodies, sid, 0, 3)                                   # ranks 0..2 own one body each, rank 3 none
+        mw.upload(bodies, sid, 0, 3)                                   # fewer bodies than ranks: some shards stay empty
         for _ in range(20):
             mw.step(DT, 5)
         got = mw.download()
@@ -232,7 +328,6 @@ def test_multi_world_edge_cases():
         assert bits_equal(one, want)
         bad = big.copy()
         bad[7, 31] = np.nan
-        mw.upload(bad, big_sid, 0, 90)                                 # the plan itself copes (NaN cells are clamped) ...
-        with pytest.raises(capi.XpbdError) as e:                       # ... but a NaN position has left every margin
-            mw.step(DT, 5)
-        assert e.value.code == capi.E_HALO
+        with pytest.raises(capi.XpbdError) as e:                       # a body without a position cannot be given to a shard
+            mw.upload(bad, big_sid, 0, 90)
+        assert e.value.code == capi.E_INVALID and "non-finite" in str(e.value)

@@ -111,3 +111,57 @@ def _outrun_worker(rank, world_size, port, out_dir):
 def test_python_halo_loop_detects_a_body_that_outruns_the_margin(tmp_path):
     mp.spawn(_outrun_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
     assert np.load(tmp_path / "raised0.npy")[0] and np.load(tmp_path / "raised1.npy")[0]
+
+
+def _library_worker(rank, world_size, port, out_dir, n, seed, substeps, frames, pitch):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from constraint_solver_amd.distributed import ShardedContactWorld
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        kind = capi.SCENE_BOXES_DROP
+        bodies, sid, joints = _shuffled_line(n, seed, pitch)
+        polys, radius, centroid = hc.shape_tables(capi, kind)
+        world = ShardedContactWorld(hc.OracleBackend(ob, hc.POLY_NAMES[kind], 0.02), rank, world_size, bodies, sid, radius, centroid,
+                                    pad=0.02, halo_margin=0.75, joints_global=joints, order="library", replan_every=1)
+        ghosts0 = [len(g) for g in world.plan.ghosts]
+        owners0 = world.plan._owner.copy()
+        for _ in range(frames):
+            world.step(hc.DT, substeps)
+        state = world.gather_global_in_caller_order()
+        if rank == 0:
+            np.save(os.path.join(out_dir, "sharded.npy"), state)
+            np.save(os.path.join(out_dir, "ghosts.npy"), np.array(ghosts0))
+            np.save(os.path.join(out_dir, "owners.npy"), np.stack([owners0, world.plan._owner]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _shuffled_line(n, seed, pitch):
+    """halo_common.line_scene with its bodies numbered at random (and the chain joints re-indexed accordingly)."""
+    kind = capi.SCENE_BOXES_DROP
+    bodies, sid = hc.line_scene(capi, kind, n, seed, pitch)
+    joints = hc.chain_joints(capi, n, every=1, distance=pitch, limit=n // 2)
+    perm = np.random.default_rng(seed).permutation(n)              # caller's index k holds grid body perm[k]
+    inverse = np.empty_like(perm)
+    inverse[perm] = np.arange(n)
+    joints["body_a"], joints["body_b"] = inverse[joints["body_a"]], inverse[joints["body_b"]]
+    return bodies[perm], sid[perm], joints
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_library_owned_partition_of_a_shuffled_scene_equals_the_single_run_in_the_callers_order(tmp_path, world_size):
+    """order="library" (what xpbd_multi_world_upload does): the caller's numbering is random, the shards are cut from the
+    spatial-hash cell order and re-cut at every re-plan; bodies keep their numbers, so the result is the single-process
+    run over the caller's bodies, bit for bit -- no renumbering -- and the halos are as thin as for a pre-ordered scene."""
+    n, seed, substeps, frames, pitch = 96, 3, 8, 12, 1.15
+    mp.spawn(_library_worker, args=(world_size, free_port(), str(tmp_path), n, seed, substeps, frames, pitch), nprocs=world_size, join=True)
+    bodies, sid, joints = _shuffled_line(n, seed, pitch)
+    want = hc.expected(ob, bodies, sid, capi.SCENE_BOXES_DROP, substeps, frames, 0.02, joints)
+    got, ghosts, owners = np.load(tmp_path / "sharded.npy"), np.load(tmp_path / "ghosts.npy"), np.load(tmp_path / "owners.npy")
+    assert bits_equal(got, want)
+    assert 0 < ghosts.max() < n // 4                                 # slabs of space although the indices are shuffled
+    counts = np.bincount(owners[0], minlength=world_size)
+    assert counts.max() - counts.min() <= n // world_size // 2       # near-equal shares
+    assert np.abs(want[:, 22:25]).max() < 30.0                       # the scene stayed within the halo contract

@@ -109,3 +109,77 @@ def test_far_bodies_are_more_than_two_cells_from_every_foreign_body(layout):
         n_far += int(far.sum())
     if layout == "slabs":
         assert n_far > 0.3 * n
+
+
+# ---- ownership is the library's: the x-major cell sequence cut into runs of near-equal body count ---------------------------
+def _cloud_keys(rng, n, extent, edge):
+    centre = rng.uniform(0, extent, (n, 3)) * np.array([1.0, 0.4, 0.1])
+    return centre, np.array([capi.halo_cell_key(c, edge) for c in centre], dtype=np.int64)
+
+
+@pytest.mark.parametrize("world_size", [2, 3, 4, 8])
+@pytest.mark.parametrize("n,extent,edge", [(2000, 60.0, 2.8), (997, 12.0, 2.8), (64, 1.0, 2.8), (5, 30.0, 2.8)])
+def test_native_partition_equals_python_partition_and_is_balanced(world_size, n, extent, edge):
+    from constraint_solver_amd.distributed import cell_keys, partition_owner
+    rng = np.random.default_rng(n + world_size)
+    centre, keys = _cloud_keys(rng, n, extent, edge)
+    assert np.array_equal(keys, cell_keys(centre, edge))
+    owner = capi.halo_partition(keys, world_size)
+    assert np.array_equal(owner, partition_owner(keys, world_size))
+    # slabs: in (key, index) order the owners never decrease
+    order = np.lexsort((np.arange(n), keys))
+    assert np.all(np.diff(owner[order].astype(np.int64)) >= 0)
+    # balance: every cut lies within a quarter of a share of its ideal position
+    counts = np.bincount(owner, minlength=world_size)
+    assert counts.sum() == n
+    share = max(1, n // world_size)
+    ideal = np.array([n // world_size + (1 if r < n % world_size else 0) for r in range(world_size)])
+    assert np.all(np.abs(np.cumsum(counts) - np.cumsum(ideal)) <= share / 4 + 1)
+    # a cell is split between two ranks only where keeping it whole would have cost more than that
+    if extent >= 12.0 and n >= 900:
+        split = sum(len(set(owner[keys == k].tolist())) > 1 for k in np.unique(keys))
+        assert split <= world_size - 1
+
+
+def test_partition_does_not_depend_on_the_callers_numbering_of_cells():
+    """The same bodies numbered differently: every CELL ends up with the same owner (only a split cell's bodies may differ)."""
+    rng = np.random.default_rng(3)
+    n, world_size = 3000, 4
+    _, keys = _cloud_keys(rng, n, 80.0, 2.8)
+    perm = rng.permutation(n)
+    a, b = capi.halo_partition(keys, world_size), capi.halo_partition(keys[perm], world_size)
+    whole = [k for k in np.unique(keys) if len(set(a[keys == k].tolist())) == 1]
+    assert len(whole) > 0.95 * len(np.unique(keys))
+    for k in whole:
+        assert set(b[keys[perm] == k].tolist()) == set(a[keys == k].tolist())
+
+
+@pytest.mark.parametrize("world_size", [2, 4])
+def test_native_plan_with_library_owners_equals_python_plan(world_size):
+    rng = np.random.default_rng(17)
+    n = 1200
+    polys = capi.scene_polytopes(capi.SCENE_MIXED_DROP)
+    radius = np.array([np.linalg.norm(p["vertices"] - p["centroid"], axis=1).max() for p in polys])
+    centroid = np.array([p["centroid"] for p in polys])
+    bodies, sid = capi.scene_pile(capi.SCENE_MIXED_DROP, 3, n, 1.4, 3)
+    perm = rng.permutation(n)                                      # the caller's numbering has nothing to do with space
+    bodies, sid = bodies[perm], sid[perm]
+    a = rng.choice(n - 200, 40, replace=False)
+    joints = np.zeros(40, dtype=capi.JOINT_DTYPE)
+    joints["body_a"], joints["body_b"] = a, a + rng.integers(1, 200, 40)
+    centre, rad = bounding_spheres(bodies, sid, radius, centroid)
+    pad, margin = 0.02, 0.5
+    pairs = np.stack([joints["body_a"], joints["body_b"]], axis=1).astype(np.int64)
+    plan = HaloPlan(centre, rad, world_size, margin, pad, joint_pairs=pairs, owner="library")
+    keys = keys_of(centre, rad, pad, margin)
+    owner = capi.halo_partition(keys, world_size)
+    assert np.array_equal(owner, plan._owner)
+    ghosts_index_ranges = 0
+    for rank in range(world_size):
+        ghosts, boundary, far = capi.halo_plan_owned(keys, owner, world_size, rank, joints, with_far=True)
+        assert np.array_equal(ghosts, np.sort(plan.ghosts[rank]))
+        assert np.array_equal(boundary, plan.boundary[rank])
+        assert len(far) == len(plan.own_ids[rank]) and not np.any(far[np.isin(plan.own_ids[rank], boundary)])
+        ghosts_index_ranges += len(capi.halo_plan(keys, world_size, rank, joints)[0])
+    total = sum(len(g) for g in plan.ghosts)
+    assert 0 < total < 0.5 * ghosts_index_ranges                   # slabs of space, not index ranges of a shuffled scene
