@@ -164,9 +164,12 @@ def hip_lib():
         L.xpbd_multi_world_download.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.xpbd_multi_world_halo_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), _f64p]
         L.xpbd_multi_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-        L.xpbd_multi_world_download_owned.argtypes = [C.c_void_p, _u32p, C.c_void_p, C.c_uint32, _u32p]
-        L.xpbd_multi_world_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-        L.xpbd_multi_world_owners.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        try:
+            L.xpbd_multi_world_download_owned.argtypes = [C.c_void_p, _u32p, C.c_void_p, C.c_uint32, _u32p]
+            L.xpbd_multi_world_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            L.xpbd_multi_world_owners.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        except AttributeError:          # an older build loaded through XPBD_HIP_LIB for an A/B measurement (scripts/)
+            pass
         L.xpbd_halo_cell_key.argtypes = [_f64p, C.c_double]
         L.xpbd_halo_cell_key.restype = C.c_int64
         L.xpbd_halo_plan.argtypes = [C.POINTER(C.c_int64), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p,

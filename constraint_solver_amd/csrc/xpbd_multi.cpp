@@ -8,8 +8,9 @@
 // every GPU of the node: what a Rust host would do) or one each (one process per GPU, the ranks of a launcher).
 //
 // Ownership is the LIBRARY's: at every plan the bodies are binned into the cells of a uniform grid (edge = 2 * (largest
-// bounding radius + pad + halo_margin)), the cells are ordered x-major (the spatial-hash cell key) and that sequence is cut
-// into n_ranks runs of near-equal body count -- every rank owns a slab of space, whatever order the caller numbered its
+// bounding radius + pad + halo_margin)), the cells are ordered by their spatial-hash cell key taken along the LONGEST axis of
+// the world first, and that sequence is cut into n_ranks runs of near-equal body count -- every rank owns a slab of space
+// across the world's longest axis, whatever order the caller numbered its
 // bodies in, and a re-plan re-balances the slabs as a pile migrates (bodies change owner then).  A shard is an ordinary
 // xpbd_world in XPBD_MODE_CONTACTS holding its OWNED bodies plus GHOST copies of the remote bodies that can reach an owned
 // body before the next plan, in ascending GLOBAL id (the caller's numbering) -- so every neighbour list and every
@@ -143,7 +144,34 @@ void multiselect(int64_t *a, size_t lo, size_t hi, const size_t *pos, size_t n_p
     multiselect(a, pos[mid] + 1, hi, pos + mid + 1, n_pos - mid - 1);
 }
 
-// cuts[r] for r = 1 .. w - 1 (cuts[0] = the smallest possible pair); a deterministic function of the keys alone
+// The slabs are cut ACROSS THE LONGEST AXIS of the world's box of cells (a world 64 cells by 256 gets four slabs of 64 x 64,
+// not of 16 x 256: a quarter of the boundary): `order` = the axes by falling extent (ties: x, y, z), and the bodies are
+// sequenced by their cell key re-packed with the axes in that order.
+void slab_axes(const int64_t *keys, uint32_t n, int order[3])
+{
+    int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+    for (uint32_t g = 0; g < n; ++g) {
+        int64_t c[3];
+        cell_of_key(keys[g], c);
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a]);
+            hi[a] = std::max(hi[a], c[a]);
+        }
+    }
+    order[0] = 0, order[1] = 1, order[2] = 2;
+    if (n == 0)
+        return;
+    std::stable_sort(order, order + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
+}
+
+int64_t slab_key(int64_t key, const int order[3])
+{
+    int64_t c[3];
+    cell_of_key(key, c);
+    return cell_key(c[order[0]], c[order[1]], c[order[2]]);
+}
+
+// cuts[r] for r = 1 .. w - 1 (cuts[0] = the smallest possible pair) over the SLAB keys; a deterministic function of the keys alone
 void partition_cuts(const int64_t *keys, uint32_t n, uint32_t w, std::vector<Cut> &cuts)
 {
     cuts.assign(w, Cut{INT64_MIN, 0});
@@ -664,9 +692,14 @@ int make_plan(xpbd_multi_world *mw)
     uint64_t migrated = 0;
     if (st.ok()) {
         std::vector<Cut> cuts;
-        partition_cuts(keys.data(), n, w, cuts);
+        int axes[3];
+        slab_axes(keys.data(), n, axes);
+        std::vector<int64_t> slab(n);
+        for (uint32_t g = 0; g < n; ++g)
+            slab[g] = slab_key(keys[g], axes);
+        partition_cuts(slab.data(), n, w, cuts);
         for (uint32_t g = 0; g < n; ++g) {
-            owner[g] = (uint8_t)owner_of(cuts, keys[g], g);
+            owner[g] = (uint8_t)owner_of(cuts, slab[g], g);
             ++owned_count[owner[g]];
             migrated += owner[g] != holder[g];
         }
@@ -1502,9 +1535,14 @@ int xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n_
     if ((n_global && (!cell_keys || !owner)) || n_ranks == 0 || n_ranks > 64)
         return set_error(XPBD_E_INVALID, "xpbd_halo_partition: bad argument");
     std::vector<Cut> cuts;
-    partition_cuts(cell_keys, n_global, n_ranks, cuts);
+    int axes[3];
+    slab_axes(cell_keys, n_global, axes);
+    std::vector<int64_t> slab(n_global);
     for (uint32_t g = 0; g < n_global; ++g)
-        owner[g] = (uint8_t)owner_of(cuts, cell_keys[g], g);
+        slab[g] = slab_key(cell_keys[g], axes);
+    partition_cuts(slab.data(), n_global, n_ranks, cuts);
+    for (uint32_t g = 0; g < n_global; ++g)
+        owner[g] = (uint8_t)owner_of(cuts, slab[g], g);
     return XPBD_OK;
 }
 

@@ -9,7 +9,7 @@ Scheme
 ------
 * Ownership: order="library" (what the native world does, csrc/xpbd_multi.cpp): the x-major sequence of
   spatial-hash cells is cut into world_size runs of near-equal body count (partition_owner), so every rank
-  owns a slab of space whatever the caller's numbering, and a re-plan re-balances the slabs; bodies keep
+  owns a slab of space (across the world's longest axis) whatever the caller's numbering, and a re-plan re-balances the slabs; bodies keep
   the caller's numbering and results equal a single-device run over the caller's bodies, bit for bit.
   Older forms, kept: contiguous index ranges (sharding.shard_range) of the caller's body order
   (order="index") or of the bodies renumbered by cell (order="spatial": results equal a single-device
@@ -78,6 +78,12 @@ def partition_owner(key, world_size):
     owner = np.zeros(n, dtype=np.uint8)
     if n == 0 or world_size < 2:
         return owner
+    # slabs across the LONGEST axis of the world's box of cells: re-pack the keys with the axes by falling extent (ties: x, y, z)
+    bias, mask = 1 << 20, (1 << 21) - 1
+    cell = np.stack([(key >> 42) - bias, ((key >> 21) & mask) - bias, (key & mask) - bias], axis=1)
+    extent = cell.max(axis=0) - cell.min(axis=0)
+    axes = sorted(range(3), key=lambda a: -int(extent[a]))          # (stable)
+    key = HaloPlan._key(cell[:, axes])
     order = np.lexsort((np.arange(n), key))
     sk = key[order]
     share = max(1, n // world_size)

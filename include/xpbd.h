@@ -304,9 +304,9 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
  * Multi-GPU world (EXTENSION): the caller is still World::integrate (src/world.rs:34-43), now over an N-body
  * world in XPBD_MODE_CONTACTS whose bodies are sharded over the GPUs of one node.  The caller numbers its bodies as it likes:
  * OWNERSHIP IS THE LIBRARY'S.  At every plan the bodies are binned into a uniform grid (cell edge = 2 * (largest bounding
- * radius + contact_pad + halo_margin)), the cells are ordered by spatial-hash cell key (x-major) and that sequence is cut
- * into n_ranks runs of near-equal body count: every rank owns a slab of space; a re-plan re-balances the slabs (bodies
- * change owner as a pile migrates).  Bodies keep the caller's numbering everywhere in this interface.
+ * radius + contact_pad + halo_margin)), the cells are ordered by spatial-hash cell key, longest axis of the world first, and
+ * that sequence is cut into n_ranks runs of near-equal body count: every rank owns a slab of space across the world's
+ * longest axis; a re-plan re-balances the slabs (bodies change owner as a pile migrates).  Bodies keep the caller's numbering everywhere in this interface.
  * One xpbd_multi_world drives this process's LOCAL shards of the n_ranks shards of the world: all of them (one process owns
  * every GPU) or one each (one process per GPU).  Every shard steps its owned bodies plus ghost copies of the remote
  * bodies within reach, and after EVERY substep the boundary bodies' 13 dynamic doubles travel in ONE all-gather (RCCL over
@@ -396,8 +396,8 @@ int  xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10]);
 int  xpbd_multi_world_owners(xpbd_multi_world *mw, uint8_t *owner, uint32_t n_global);
 int  xpbd_multi_world_contact_stats(xpbd_multi_world *mw, uint64_t out[3]);             /* sums of xpbd_world_contact_stats */
 /* Diagnostics, host only (no device needed), exactly as the plans compute them.  The grid cell key of a bounding-sphere
- * centre (x-major: ascending keys are slabs along x); the owner of every body from the cell keys of all bodies (the key
- * sequence cut into n_ranks runs of near-equal body count, on cell boundaries unless a rank would end up more than a quarter
+ * centre; the owner of every body from the cell keys of all bodies (the keys
+ * re-packed with the longest axis of the cells' bounding box first, that sequence cut into n_ranks runs of near-equal body count, on cell boundaries unless a rank would end up more than a quarter
  * of its share off balance -- then the cell is split by body index); and one rank's halo plan from keys and owners (ascending
  * ghost ids: the remote bodies it mirrors; ascending boundary ids: its own bodies that others mirror; far (optional): per
  * owned body in ascending index, 1 if no foreign body lies within two cells, so that it may travel halo_margin + half a cell

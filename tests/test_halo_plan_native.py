@@ -126,9 +126,13 @@ def test_native_partition_equals_python_partition_and_is_balanced(world_size, n,
     assert np.array_equal(keys, cell_keys(centre, edge))
     owner = capi.halo_partition(keys, world_size)
     assert np.array_equal(owner, partition_owner(keys, world_size))
-    # slabs: in (key, index) order the owners never decrease
+    # slabs across the longest axis (x here): in (key, index) order the owners never decrease
     order = np.lexsort((np.arange(n), keys))
     assert np.all(np.diff(owner[order].astype(np.int64)) >= 0)
+    # ... and for the same cloud turned so that y is its longest axis the bodies get the same owners
+    turned = np.array([capi.halo_cell_key(c[[1, 0, 2]], edge) for c in centre], dtype=np.int64)
+    assert np.array_equal(capi.halo_partition(turned, world_size), owner)
+    assert np.array_equal(partition_owner(turned, world_size), owner)
     # balance: every cut lies within a quarter of a share of its ideal position
     counts = np.bincount(owner, minlength=world_size)
     assert counts.sum() == n
