@@ -218,7 +218,7 @@ def sample_of(np, total, layers, sample):
 
 
 def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pitch, rank, local_rank, world_size, steps, warmup,
-                 with_cpu, layers=0):
+                 with_cpu, layers=0, name=None):
     """One contact-pipeline measurement on a world of its own: pre-roll, warm-up, K timed frames.  Returns the result
     object (rank 0) -- value, roofline of a whole substep, cpu_baseline -- or None."""
     kind = getattr(capi, SCENE_KIND[scene])
@@ -262,6 +262,14 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
         # 48 B written once and read twice.
         substep_bytes = count * 716 + pairs * 120 + touching_ps * 72 + points_ps * 144
         achieved = substep_bytes / substep_s / 1e9
+        # ... and the ALGORITHMIC bytes of SURVEY.md 8(d): 412 B per body.substep (the pinned path) + per candidate pair two
+        # 56-byte pose reads and one manifold write of up to 4 x 56 B = 336 B
+        survey_bytes = count * 412 + pairs * 336
+        traffic = traffic_note = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile) and name:                # PMC counters cannot be read from inside the run: the committed pass
+            entry = json.load(open(tfile)).get("contacts", {}).get(name, {})
+            traffic, traffic_note = entry.get("bytes_per_substep"), entry.get("source")
         end_state = world.download()
         speed = np.linalg.norm(end_state[:, 22:25], axis=1)
         result = {
@@ -278,9 +286,11 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
                                                     float(np.nanmax(speed))],
                        "extension": "body-body contacts: NOT in the reference (parity unpinned)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "one substep: narrowphase + k_pair_solve_integrate_ground", "launch_us": substep_s * 1e6,
                          "bytes_per_launch": substep_bytes,
+                         "achieved_survey_8d": survey_bytes / substep_s / 1e9, "frac_survey_8d": survey_bytes / substep_s / 1e9 / HBM_PEAK_GBPS,
+                         "bytes_per_launch_survey_8d": survey_bytes,
                          "note": "whole-substep figure from the byte model of DESIGN.md 8 (the narrowphase is f64-VALU / latency "
                                  "bound, the per-body kernel bandwidth bound; per-kernel times in profiles/)"},
             "cpu_baseline": None,
@@ -296,10 +306,10 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
 def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank, local_rank,
                          world_size, steps, warmup, local_shards=0):
     """EXTENSION, N > 1: body-body contacts through the NATIVE multi-GPU world (xpbd_multi_world_*, csrc/xpbd_multi.cpp):
-    every rank owns a contiguous index range = a slab of space (whole grid rows; for a pile, a pile of its own laid next
-    to its neighbours'), steps owned + ghost bodies, and the boundary bodies travel in one ncclAllGather per substep
-    (RCCL over xGMI); the halo plan is built by the library, a body outrunning halo_margin is an error.  Each rank
-    generates ONLY its own bodies.  local_shards > 0: rehearsal on one GPU -- that many shards in THIS process on device 0
+    every rank hands over its index slice of the scene (generating ONLY those bodies); the library cuts the shards -- slabs
+    of space across the world's longest axis, near-equal body counts, re-balanced at every re-plan -- moves each body to
+    its owner, steps owned + ghost bodies, and the boundary bodies travel in one ncclAllGather per substep (RCCL over
+    xGMI); a frame in which a body outruns halo_margin is undone, re-planned and run again.  local_shards > 0: rehearsal on one GPU -- that many shards in THIS process on device 0
     with the in-process transport.  Not in the reference; parity = sharded == single device (tests/test_gpu_multi.py)."""
     import torch.distributed as dist
     from constraint_solver_amd.sharding import shard_range
@@ -350,9 +360,11 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
             "steps": steps, "warmup": warmup, "preroll_frames": preroll,
             "config": {"workload": contacts_workload(scene, bodies, args.substeps, narrowphase, joints_n, pitch, layers),
                        "bodies_per_gpu": bodies, "bodies_total": total, "substeps": args.substeps, "scene": scene,
-                       "sharding": "contiguous index ranges = slabs of space, owned + ghost bodies per rank; halo plan, per-frame "
-                                   "halo-validity check and one all-gather per substep inside xpbd_multi_world_step (%s)" % transport,
-                       "halo": halo, "neighbour_pairs_here": pairs, "touching_pairs_per_substep_here": touching / n_sub,
+                       "sharding": "shards cut by the library from the spatial-hash cell order (slabs across the world's longest axis, "
+                                   "near-equal body counts, re-balanced at re-plans), owned + ghost bodies per rank; halo plan, end-of-frame "
+                                   "halo-validity check (a violating frame is undone and re-run) and one all-gather per substep inside "
+                                   "xpbd_multi_world_step (%s)" % transport,
+                       "halo": halo, "plan": world.plan_stats(), "neighbour_pairs_here": pairs, "touching_pairs_per_substep_here": touching / n_sub,
                        "manifold_points_per_substep_here": points / n_sub,
                        "extension": "not in the reference (parity unpinned; sharded == single device bit for bit)"},
             "roofline": None, "cpu_baseline": None,
@@ -501,7 +513,7 @@ def main():
         for name, cfg in sub_runs.items():
             try:
                 r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
-                                 steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=False, **cfg)
+                                 steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=False, name=name, **cfg)
             except capi.XpbdError as e:                     # e.g. XPBD_E_HALO in a scene that outruns its margin
                 r = {"error": str(e)}
             subs[name] = r
@@ -514,7 +526,7 @@ def main():
         if args.only not in sub_runs:
             raise SystemExit("--only: one of pinned, %s" % ", ".join(sub_runs))
         r = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size, steps=args.steps,
-                         warmup=args.warmup, with_cpu=False, **sub_runs[args.only])
+                         warmup=args.warmup, with_cpu=False, name=args.only, **sub_runs[args.only])
         if rank == 0:
             print(json.dumps({"metric": METRIC, "n_gpus": world_size, **r}), flush=True)
         barrier()
@@ -712,12 +724,36 @@ def main():
             for name, cfg in sub_runs.items():
                 try:
                     subs[name] = run_contacts(capi, np, torch, args, rank=rank, local_rank=local_rank, world_size=world_size,
-                                              steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, **cfg)
+                                              steps=min(args.steps, 30), warmup=min(args.warmup, 10), with_cpu=with_cpu, name=name, **cfg)
                 except capi.XpbdError as e:
                     subs[name] = {"error": str(e)}
         if rank == 0:
             result["contacts"] = subs
     if rank == 0:
+        # The north-star numbers once more, short and LAST on the line (a long line is kept from its tail): body.substeps/s of
+        # the workloads BASELINE.json names -- box stacks with SAT contacts, mixed convex polyhedra on GJK/EPA, bodies + joints --
+        # with the fraction of the 8 TB/s HBM roof at SURVEY.md 8(d)'s algorithmic bytes, next to the pinned headline.
+        subs = result.get("contacts") or {}
+
+        def brief(key):
+            r = subs.get(key) or {}
+            if "value" not in r:
+                return {"error": r.get("error", "not run")} if r else None
+            roof = r.get("roofline") or {}
+            return {"value": r["value"], "us_per_substep": roof.get("launch_us"), "frac_hbm_survey_8d": roof.get("frac_survey_8d"),
+                    "frac_hbm_byte_model": roof.get("frac")}
+        hbm = result.get("roofline_hbm_resident") or {}
+        result["north_star"] = {
+            "unit": UNIT, "n_gpus": world_size,
+            "pinned_262144_fused": {"value": result["value"], "frac_hbm": result["roofline"]["frac"],
+                                    "f64_pipe_busy": (result["roofline"].get("valu") or {}).get("pipe_busy")},
+            "pinned_hbm_resident": {"bodies": hbm.get("bodies"), "frac_hbm": hbm.get("frac"), "frac_of_access_pattern": hbm.get("frac_of_access_pattern")}
+            if hbm else None,
+            "stacks_sat": brief("stacks_262144_sat"), "stacks_gjk_epa": brief("stacks_262144_gjk_epa"),
+            "boxes_pile_sat": brief("boxes_pile_262144_sat"), "mixed_gjk_epa": brief("mixed_pile_65536_gjk_epa"),
+            "mixed_sat": brief("mixed_pile_65536_sat"), "joints": brief("boxes_262144_joints_65536"),
+            "cpu_1_thread": (result.get("cpu_baseline") or {}).get("value"),
+        }
         print(json.dumps(result), flush=True)
     barrier()
     if world_size > 1:

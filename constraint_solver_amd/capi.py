@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
     "xpbd_world_set_sat_schedule",
     "xpbd_world_edge_axes_separation",
-    "xpbd_selftest_hbm_copy", "xpbd_selftest_field_streams", "xpbd_world_snapshot_positions", "xpbd_world_max_displacement2",
+    "xpbd_selftest_hbm_copy", "xpbd_selftest_field_streams", "xpbd_selftest_gather", "xpbd_world_snapshot_positions", "xpbd_world_max_displacement2",
     "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
     "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
     "xpbd_multi_world_synchronize", "xpbd_multi_world_download", "xpbd_multi_world_halo_stats", "xpbd_multi_world_contact_stats",
@@ -605,6 +605,15 @@ def selftest_div_sqrt(a, b, device=0):
     q, s = np.empty_like(a), np.empty_like(a)
     _check(hip_lib().xpbd_selftest_div_sqrt(device, _f64(a), _f64(b), _f64(q), _f64(s), a.size))
     return q, s
+
+
+def selftest_gather(records, record_bytes, read_bytes, repeats=5, device=0):
+    """GB/s of a gather of known size (every record read once, 16-byte loads): the FETCH_SIZE calibration kernel."""
+    out = C.c_double(0.0)
+    L = hip_lib()
+    L.xpbd_selftest_gather.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f64p]
+    _check(L.xpbd_selftest_gather(device, records, record_bytes, read_bytes, repeats, C.byref(out)))
+    return out.value
 
 
 def selftest_hbm_copy(nbytes=1 << 31, repeats=10, device=0):

@@ -83,6 +83,10 @@ hipError_t launch_copy16(const void *src, void *dst, size_t bytes, uint32_t vari
 // written per body, in the world's field-major layout (base[f * stride + i]) or tile-major (64 bodies x all fields contiguous).
 hipError_t launch_field_streams(const double *in, double *out, size_t bodies, bool tile_major, hipStream_t stream);
 
+// Diagnostics: lane i reads the first read_bytes of record perm(i) (records: a power of two >= 256; record_bytes / read_bytes:
+// one of the pairs instantiated in xpbd_kernels.hip) with 16-byte loads and writes one double.
+hipError_t launch_gather_records(const void *in, double *out, uint32_t records, uint32_t record_bytes, uint32_t read_bytes, hipStream_t stream);
+
 // Diagnostics: q = a / b, r = sqrt(a), element-wise, all device pointers.
 hipError_t launch_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, uint32_t n,
                                     hipStream_t stream);

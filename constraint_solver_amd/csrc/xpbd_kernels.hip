@@ -354,6 +354,50 @@ hipError_t launch_field_streams(const double *in, double *out, size_t bodies, bo
     return hipGetLastError();
 }
 
+namespace {
+// A GATHER of known size (xpbd_selftest_gather): lane i reads the first READ 16-byte words of record perm(i) of `records`
+// records of REC words each -- every record exactly once (perm = multiplication by an odd constant modulo a power of two),
+// so no byte is served twice -- and writes one double.  The contact kernels read their body records, mass properties and
+// manifolds this way; running this under `rocprofv3 --pmc FETCH_SIZE` calibrates that counter for gathered 16-byte loads
+// (the guide calibrates it for wide coalesced streams only).
+template <uint32_t READ, uint32_t REC>
+__global__ void __launch_bounds__(256) k_gather_records(const double2 *__restrict__ in, double *__restrict__ out, uint32_t mask)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t rec = (i * 2654435761u) & mask;
+    const double2 *r = in + (size_t)rec * REC;
+    double2 v[READ];
+#pragma unroll
+    for (uint32_t k = 0; k < READ; ++k)
+        v[k] = r[k];
+    double acc = 0.0;
+#pragma unroll
+    for (uint32_t k = 0; k < READ; ++k)
+        acc += v[k].x + v[k].y;
+    out[i] = acc;
+}
+} // namespace
+
+hipError_t launch_gather_records(const void *in, double *out, uint32_t records, uint32_t record_bytes, uint32_t read_bytes, hipStream_t stream)
+{
+    const dim3 grid(records / 256), block(256);
+    const double2 *src = static_cast<const double2 *>(in);
+    const uint32_t mask = records - 1;
+#define XPBD_GATHER_CASE(READ, REC)                                                                      \
+    if (read_bytes == (READ) * 16 && record_bytes == (REC) * 16) {                                        \
+        hipLaunchKernelGGL((k_gather_records<READ, REC>), grid, block, 0, stream, src, out, mask);       \
+        return hipGetLastError();                                                                         \
+    }
+    XPBD_GATHER_CASE(8, 8)    // a whole 128-byte record (StatRecord)
+    XPBD_GATHER_CASE(4, 8)    // the first 64 bytes of a 128-byte record
+    XPBD_GATHER_CASE(1, 8)    // 16 bytes of a 128-byte record
+    XPBD_GATHER_CASE(12, 12)  // a whole 192-byte record (BodyRecord: every other one straddles two 128-byte lines)
+    XPBD_GATHER_CASE(4, 12)   // the first 56..64 bytes of a BodyRecord (what the narrowphase reads)
+    XPBD_GATHER_CASE(8, 16)   // the first line of a 256-byte record (a manifold of up to four points)
+#undef XPBD_GATHER_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_copy16(const void *src, void *dst, size_t bytes, uint32_t variant, hipStream_t stream)
 {
     const size_t n16 = bytes / 16;

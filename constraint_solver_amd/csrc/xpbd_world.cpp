@@ -1546,6 +1546,43 @@ int xpbd_selftest_hbm_copy(int32_t device, uint64_t bytes, uint32_t repeats, dou
     return XPBD_OK;
 }
 
+int xpbd_selftest_gather(int32_t device, uint32_t records, uint32_t record_bytes, uint32_t read_bytes, uint32_t repeats, double *gbytes_per_s)
+{
+    if (!gbytes_per_s || records < 256 || (records & (records - 1)) != 0 || repeats == 0 || read_bytes > record_bytes)
+        return fail(XPBD_E_INVALID, "xpbd_selftest_gather: records must be a power of two >= 256, read_bytes <= record_bytes");
+    *gbytes_per_s = 0.0;
+    XPBD_HIP_TRY(hipSetDevice(device));
+    const size_t in_bytes = (size_t)records * record_bytes, out_bytes = (size_t)records * 8;
+    DeviceBuffer in, out;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = in.reserve(in_bytes);
+    if (e == hipSuccess) e = out.reserve(out_bytes);
+    if (e == hipSuccess) e = hipMemset(in.ptr, 0, in_bytes);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best_ms = 0.0f;
+    for (uint32_t k = 0; k < repeats + 1 && e == hipSuccess; ++k) { // (the first launch warms up and is not counted)
+        e = hipEventRecord(e0, nullptr);
+        if (e == hipSuccess) e = xpbd::launch_gather_records(in.ptr, out.as<double>(), records, record_bytes, read_bytes, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && k > 0 && (k == 1 || ms < best_ms))
+            best_ms = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    in.release();
+    out.release();
+    if (e == hipErrorInvalidValue)
+        return fail(XPBD_E_INVALID, "xpbd_selftest_gather: no kernel for %u bytes read of %u-byte records", read_bytes, record_bytes);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? XPBD_E_OOM : XPBD_E_HIP, "xpbd_selftest_gather: %s", hipGetErrorString(e));
+    *gbytes_per_s = ((double)records * read_bytes + (double)out_bytes) / ((double)best_ms * 1e-3) / 1e9;
+    return XPBD_OK;
+}
+
 int xpbd_selftest_field_streams(int32_t device, uint64_t bodies, uint32_t tile_major, uint32_t repeats, double *gbytes_per_s)
 {
     if (!gbytes_per_s || bodies < 64 || bodies > (1ull << 28) || repeats == 0)

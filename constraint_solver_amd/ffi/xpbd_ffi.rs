@@ -171,6 +171,7 @@ extern "C" {
     pub fn xpbd_selftest_div_sqrt(device: i32, a: *const f64, b: *const f64, q: *mut f64, r: *mut f64, n: u32) -> c_int;
     pub fn xpbd_selftest_hbm_copy(device: i32, bytes: u64, repeats: u32, gbytes_per_s: *mut f64) -> c_int;
     pub fn xpbd_selftest_field_streams(device: i32, bodies: u64, tile_major: u32, repeats: u32, gbytes_per_s: *mut f64) -> c_int;
+    pub fn xpbd_selftest_gather(device: i32, records: u32, record_bytes: u32, read_bytes: u32, repeats: u32, gbytes_per_s: *mut f64) -> c_int;
     pub fn xpbd_world_download_frames(w: *mut XpbdWorld, frames: *mut f64, n: u32) -> c_int;
     // ---- extension: body-body contacts, joints, multi-GPU halo exchange (not in the reference) ----
     pub fn xpbd_world_set_polytopes(w: *mut XpbdWorld, shapes: *const XpbdPolytope, n_shapes: u32) -> c_int;

@@ -445,6 +445,14 @@ int  xpbd_selftest_hbm_copy(int32_t device, uint64_t bytes, uint32_t repeats, do
  * two-stream copy above, is the roof of XPBD_MODE_PER_SUBSTEP on worlds beyond the Infinity Cache. */
 int  xpbd_selftest_field_streams(int32_t device, uint64_t bodies, uint32_t tile_major, uint32_t repeats, double *gbytes_per_s);
 
+/* Diagnostics: a GATHER of known size -- lane i reads the first read_bytes of record perm(i) of `records` records (a power of
+ * two) of record_bytes each with 16-byte loads, every record exactly once, and writes one double; (read_bytes, record_bytes)
+ * one of (128, 128), (64, 128), (16, 128), (192, 192), (64, 192), (128, 256): how the contact kernels read body records, mass
+ * properties and manifolds.  *gbytes_per_s = (records * read_bytes + records * 8) / best time.  Under `rocprofv3 --pmc
+ * FETCH_SIZE` this calibrates the counter for gathered loads (profiles/, scripts/fetch_calibration.py). */
+int  xpbd_selftest_gather(int32_t device, uint32_t records, uint32_t record_bytes, uint32_t read_bytes, uint32_t repeats,
+                          double *gbytes_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,7 @@
 # same command restricted to one part at a time (--only: no extras / CPU leg, so the kernel rows are the timed regime),
 # and the PMC passes, each counter group in its own run (never mixed with other trace domains).
 # Usage: scripts/gpu_profile.sh <tag> [parts...]   -> everything lands under gpurun_out/<tag>/
-#   parts: bench trace pmc pmc_big contacts_pmc  (default: bench trace pmc)
+#   parts: bench trace trace_big pmc pmc_big contacts_pmc calib  (default: bench trace pmc)
 set -eo pipefail
 TAG=${1:-prof}; shift || true
 PARTS=${*:-bench trace pmc}
@@ -28,6 +28,11 @@ pmc() { # name, "extra args", counters...
   timeout -k 10 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $B $extra > "$OUT/pmc_$name.log" 2>&1
 }
 
+pmc_cmd() { # name, counter, command...   (a counter pass over another program: the known-bytes calibration kernels)
+  local name=$1 counter=$2; shift 2
+  timeout -k 10 400 rocprofv3 --pmc $counter --output-format csv -d "$OUT/pmc_$name" -- "$@" > "$OUT/pmc_$name.log" 2>&1
+}
+
 if has bench; then
   timeout -k 10 600 $B > "$OUT/bench.json" 2> "$OUT/bench.err"
 fi
@@ -40,6 +45,15 @@ if has trace; then
   trace mixed_sat --only mixed_pile_65536_sat
   trace joints --only boxes_262144_joints_65536
   trace boxes_pile --only boxes_pile_262144_sat
+fi
+if has trace_big; then   # k_step at 2 097 152 bodies, one launch per substep: the HBM-resident roofline line, reproducible from rocprof
+  trace pinned_substep_big --only pinned --mode substep --bodies 2097152 --steps 5 --warmup 2
+fi
+if has calib; then       # FETCH_SIZE / WRITE_SIZE on kernels whose byte counts are known exactly (gathers, streams)
+  pmc_cmd calib_fetch FETCH_SIZE python3 scripts/fetch_calibration.py
+  pmc_cmd calib_write WRITE_SIZE python3 scripts/fetch_calibration.py
+  pmc_cmd calib_rdreq "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" python3 scripts/fetch_calibration.py
+  python3 scripts/fetch_calibration.py > "$OUT/calib_known.json" 2> "$OUT/calib_known.err" || true
 fi
 if has pmc; then
   pmc valu "--only pinned" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
@@ -58,6 +72,14 @@ if has contacts_pmc; then
   pmc write_stacks "--only stacks_262144_sat" WRITE_SIZE
   pmc fetch_mixed_sat "--only mixed_pile_65536_sat" FETCH_SIZE
   pmc write_mixed_sat "--only mixed_pile_65536_sat" WRITE_SIZE
+  pmc fetch_boxes_pile "--only boxes_pile_262144_sat" FETCH_SIZE
+  pmc write_boxes_pile "--only boxes_pile_262144_sat" WRITE_SIZE
+  pmc fetch_stacks_gjk "--only stacks_262144_gjk_epa" FETCH_SIZE
+  pmc write_stacks_gjk "--only stacks_262144_gjk_epa" WRITE_SIZE
+  pmc fetch_mixed_gjk "--only mixed_pile_65536_gjk_epa" FETCH_SIZE
+  pmc write_mixed_gjk "--only mixed_pile_65536_gjk_epa" WRITE_SIZE
+  pmc fetch_joints "--only boxes_262144_joints_65536" FETCH_SIZE
+  pmc write_joints "--only boxes_262144_joints_65536" WRITE_SIZE
 fi
 python3 scripts/summarize_profile.py "$OUT" > "$OUT/summary.json"
 find "$OUT" -name '*kernel_trace.csv' -delete      # the raw traces (tens of MB each) stay on the box

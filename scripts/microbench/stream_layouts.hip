@@ -54,6 +54,31 @@ int main(int argc, char **argv)
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const double bytes = (double)n * (kIn + kOut) * 8;
+    // field-major again with the stride between two fields padded off the power of two (stride = n: all 51 streams of a wave sit
+    // at the same offset modulo every power of two up to n * 8 bytes, i.e. on the same channel and bank at the same time)
+    for (size_t pad : {(size_t)0, (size_t)64, (size_t)320, (size_t)4160, (size_t)65600}) {
+        double *pin = nullptr, *pout = nullptr;
+        const size_t stride = n + pad;
+        if (hipMalloc(&pin, stride * kIn * 8) != hipSuccess || hipMalloc(&pout, stride * kOut * 8) != hipSuccess)
+            return 1;
+        hipMemset(pin, 0, stride * kIn * 8);
+        const int block = 64;
+        const dim3 grid((unsigned)((n + block - 1) / block));
+        float best = 1e30f;
+        for (int rep = 0; rep < 12; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_field_major, grid, dim3(block), 0, 0, pin, pout, stride, n);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep >= 2 && ms < best)
+                best = ms;
+        }
+        printf("field-major stride n + %6zu: %8.1f us  %6.2f TB/s\n", pad, best * 1e3, bytes / (best * 1e-3) / 1e12);
+        hipFree(pin);
+        hipFree(pout);
+    }
     for (int layout = 0; layout < 2; ++layout)
         for (int block : {64, 256}) {
             const dim3 grid((unsigned)((n + block - 1) / block));

@@ -128,13 +128,45 @@ def main(out):
                           "gfx950 correction in MI355X_MICROARCH.md)" % tag
             t[key] = r
     s["hbm_traffic"] = t
+    # FETCH_SIZE / WRITE_SIZE against kernels whose byte counts are known (scripts/fetch_calibration.py)
+    calib, gather_factor = {}, None
+    try:
+        known = json.loads(open(os.path.join(out, "calib_known.json")).read().strip().splitlines()[-1])
+    except Exception:
+        known = {}
+    if known:
+        cf, cw, cr = pmc(out, "calib_fetch", 3), pmc(out, "calib_write", 3), pmc(out, "calib_rdreq", 3)
+        for k, v in known.items():
+            row = dict(v)
+            f, w = cf.get(k, {}).get("FETCH_SIZE"), cw.get(k, {}).get("WRITE_SIZE")
+            if f:
+                row["FETCH_SIZE_KiB"] = f
+                row["requested_over_FETCH_SIZE"] = v["read_bytes_requested"] / (f * 1024.0)
+                if "record_bytes" in v:                      # bytes of the 128-byte lines the reads touch (a 192-byte record: 1.5 lines)
+                    per_rec = v["read_bytes_requested"] / v["records"]
+                    lines = v["records"] * (1.5 if v["record_bytes"] == 192 and per_rec > 64 else max(1.0, per_rec / 128.0)) * 128.0
+                    row["lines_touched_over_FETCH_SIZE"] = lines / (f * 1024.0)
+            if w:
+                row["WRITE_SIZE_KiB"] = w
+                row["written_over_WRITE_SIZE"] = v["write_bytes"] / (w * 1024.0)
+            row.update({c: x for c, x in cr.get(k, {}).items() if c.startswith("TCC_")})
+            calib[k] = row
+        whole = [calib[k].get("requested_over_FETCH_SIZE") for k in ("k_gather_records<8, 8>", "k_gather_records<12, 12>", "k_gather_records<8, 16>")]
+        whole = [x for x in whole if x]
+        if whole:
+            gather_factor = sum(whole) / len(whole)
+        s["counter_calibration"] = {"kernels": calib, "gather_factor_for_whole_records": gather_factor,
+                                    "note": "factor = known bytes / (FETCH_SIZE x 1024); 2.0 = the guide's figure for wide coalesced streams"}
     contacts = {}
-    for scene in ("stacks", "mixed_sat"):
+    for scene in ("stacks", "mixed_sat", "boxes_pile", "stacks_gjk", "mixed_gjk", "joints"):
         f, w = pmc(out, "fetch_" + scene, 400), pmc(out, "write_" + scene, 400)
         for k in f:
             if "FETCH_SIZE" in f[k] and "WRITE_SIZE" in w.get(k, {}):
-                contacts.setdefault(scene, {})[k] = {"FETCH_SIZE_KiB": f[k]["FETCH_SIZE"], "WRITE_SIZE_KiB": w[k]["WRITE_SIZE"],
-                                                     "bytes_per_launch_uncalibrated": (2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0}
+                row = {"FETCH_SIZE_KiB": f[k]["FETCH_SIZE"], "WRITE_SIZE_KiB": w[k]["WRITE_SIZE"],
+                       "bytes_per_launch_factor_2": (2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0}
+                if gather_factor:
+                    row["bytes_per_launch_gather_calibrated"] = (gather_factor * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0
+                contacts.setdefault(scene, {})[k] = row
     if contacts:
         s["contacts_traffic"] = contacts
     print(json.dumps(s, indent=1))
