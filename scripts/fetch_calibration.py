@@ -21,7 +21,7 @@ def main():
     known = {}
     for record_bytes, read_bytes in PATTERNS:
         rate = capi.selftest_gather(RECORDS, record_bytes, read_bytes, repeats=3)
-        known["k_gather_records<%d, %d>" % (read_bytes // 16, record_bytes // 16)] = {
+        known["k_gather_records<%du, %du>" % (read_bytes // 16, record_bytes // 16)] = {
             "read_bytes_requested": RECORDS * read_bytes, "write_bytes": RECORDS * 8, "records": RECORDS, "record_bytes": record_bytes,
             "launches": 4, "gbytes_per_s": rate}
     bodies = 1 << 21

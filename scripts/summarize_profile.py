@@ -151,7 +151,7 @@ def main(out):
                 row["written_over_WRITE_SIZE"] = v["write_bytes"] / (w * 1024.0)
             row.update({c: x for c, x in cr.get(k, {}).items() if c.startswith("TCC_")})
             calib[k] = row
-        whole = [calib[k].get("requested_over_FETCH_SIZE") for k in ("k_gather_records<8, 8>", "k_gather_records<12, 12>", "k_gather_records<8, 16>")]
+        whole = [calib[k].get("requested_over_FETCH_SIZE") for k in ("k_gather_records<8u, 8u>", "k_gather_records<8u, 16u>")]
         whole = [x for x in whole if x]
         if whole:
             gather_factor = sum(whole) / len(whole)
