@@ -135,8 +135,8 @@ def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphas
     start, sid = state[pick].copy(), shape_id[pick].copy()
     polys = ob.polytopes_array(poly_names)
     if joints is None:
-        joints = np.zeros(0, dtype=[("body_a", "<u4"), ("body_b", "<u4"), ("anchor_a", "<f8", (3,)), ("anchor_b", "<f8", (3,)),
-                                    ("distance", "<f8")])
+        from constraint_solver_amd import capi
+        joints = np.zeros(0, dtype=capi.JOINT_DTYPE)
     inside = np.isin(joints["body_a"], pick) & np.isin(joints["body_b"], pick)
     joints = joints[inside].copy()
     joints["body_a"], joints["body_b"] = np.searchsorted(pick, joints["body_a"]), np.searchsorted(pick, joints["body_b"])

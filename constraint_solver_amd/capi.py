@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "xpbd_world_body_count", "xpbd_world_download_frames", "xpbd_world_step", "xpbd_world_synchronize", "xpbd_world_download_contacts",
     "xpbd_world_download_contact_masks", "xpbd_world_set_stream", "xpbd_world_get_stream", "xpbd_world_set_mode",
     "xpbd_step_one", "xpbd_selftest_div_sqrt", "xpbd_world_set_polytopes", "xpbd_world_narrowphase",
-    "xpbd_world_set_contact_pad", "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
+    "xpbd_world_set_contact_pad", "xpbd_world_set_max_depenetration_speed", "xpbd_multi_world_set_max_depenetration_speed",
+    "xpbd_world_contact_stats", "xpbd_world_build_neighbours",
     "xpbd_world_download_neighbours", "xpbd_world_contacts_begin", "xpbd_world_contacts_substep",
     "xpbd_world_export_dynamic", "xpbd_world_import_dynamic", "xpbd_world_import_dynamic_rows", "xpbd_world_set_joints",
     "xpbd_world_narrowphase_gjk", "xpbd_world_set_narrowphase",
@@ -87,9 +88,10 @@ class PolytopeDesc(C.Structure):
                 ("centroid", C.c_double * 3)]
 
 
-# xpbd_joint as a numpy record (64 bytes)
+# xpbd_joint as a numpy record (120 bytes)
 JOINT_DTYPE = np.dtype([("body_a", "<u4"), ("body_b", "<u4"), ("anchor_a", "<f8", (3,)), ("anchor_b", "<f8", (3,)),
-                        ("distance", "<f8")])
+                        ("distance", "<f8"), ("axis_a", "<f8", (3,)), ("axis_b", "<f8", (3,)), ("kind", "<u4"), ("reserved", "<u4")])
+JOINT_DISTANCE, JOINT_HINGE = 0, 1
 # xpbd_gjk_result as a numpy record (96 bytes)
 GJK_DTYPE = np.dtype([("status", "<i4"), ("gjk_iterations", "<u4"), ("epa_iterations", "<u4"), ("reserved", "<u4"),
                       ("depth", "<f8"), ("normal", "<f8", (3,)), ("point_a", "<f8", (3,)), ("point_b", "<f8", (3,))])
@@ -180,6 +182,11 @@ def hip_lib():
         L.xpbd_world_narrowphase_gjk.argtypes = [C.c_void_p, _u32p, C.c_uint32, C.c_void_p]
         L.xpbd_world_set_narrowphase.argtypes = [C.c_void_p, C.c_uint32]
         L.xpbd_world_set_contact_pad.argtypes = [C.c_void_p, C.c_double]
+        try:
+            L.xpbd_world_set_max_depenetration_speed.argtypes = [C.c_void_p, C.c_double]
+            L.xpbd_multi_world_set_max_depenetration_speed.argtypes = [C.c_void_p, C.c_double]
+        except AttributeError:          # an older build loaded through XPBD_HIP_LIB
+            pass
         L.xpbd_world_contact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.xpbd_world_build_neighbours.argtypes = [C.c_void_p, C.c_double, _u32p]
         L.xpbd_world_download_neighbours.argtypes = [C.c_void_p, _u32p, _u32p, C.c_uint32]
@@ -338,6 +345,10 @@ class World:
     def set_contact_pad(self, pad):
         _check(hip_lib().xpbd_world_set_contact_pad(self._h, pad))
 
+    def set_max_depenetration_speed(self, speed):
+        """Limit on how fast a body-body contact may push its bodies apart (m/s); 0 = off = the reference's solver loop."""
+        _check(hip_lib().xpbd_world_set_max_depenetration_speed(self._h, speed))
+
     def contact_stats(self):
         """(neighbour pairs of the last step, touching pairs, manifold points) -- the last two since the previous call."""
         out = (C.c_uint64 * 3)()
@@ -475,6 +486,9 @@ class MultiWorld:
     def set_polytopes(self, polytopes):
         descs, _keep = polytope_descs(polytopes)
         _check(hip_lib().xpbd_multi_world_set_polytopes(self._h, descs, len(polytopes)))
+
+    def set_max_depenetration_speed(self, speed):
+        _check(hip_lib().xpbd_multi_world_set_max_depenetration_speed(self._h, speed))
 
     def upload(self, bodies, shape_id, first_global, n_global, joints=None):
         """bodies / shape_id: the slice of the caller's bodies this process hands over, global indices [first_global,

@@ -11,6 +11,8 @@ struct Joint {
     uint32_t body_a, body_b;
     double anchor_a[3], anchor_b[3];
     double distance;
+    double axis_a[3], axis_b[3]; // XPBD_JOINT_HINGE
+    uint32_t kind, reserved;
 };
 
 // The uniform grid of one broadphase (device, written by k_grid).
@@ -58,6 +60,7 @@ struct ContactBuffers {
     const Joint *joints;
     const uint32_t *joint_off;   // [n + 1]
     const uint32_t *joint_list;  // [2 * n_joints]
+    double max_depenetration_speed; // 0 = off: xpbd_world_set_max_depenetration_speed
 };
 
 // Which bodies a per-body kernel of the pipeline works on.  Default: all of them.  The multi-GPU world (xpbd_multi.cpp) runs

@@ -676,6 +676,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
 {
     static_assert(G == 1 || G == kMaxManifoldPoints, "one lane per body or one lane per manifold point");
     const double compliance = 1e-6 / (h * h);
+    const double limit = c.max_depenetration_speed > 0.0 ? c.max_depenetration_speed * h : 0.0;
 
     Vec3 dpos{0.0, 0.0, 0.0};
     Quat drot{0.0, 0.0, 0.0, 0.0};
@@ -721,7 +722,17 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
             const Vec3 dir = difference * (1.0 / dist);
             // w = w_incident + w_reference; IEEE addition commutes, so the order of the two bodies does not matter
             const double w = generalized_inverse_mass(self, p_self, dir) + generalized_inverse_mass(other, p_other, dir);
-            const double lambda = (dist - 0.0) / (w + compliance);
+            double error = dist;
+            if (limit > 0.0) { // xpbd_world_set_max_depenetration_speed (uniform over the launch; 0 = off); oracle: accumulate_point
+                const double len = length(correction);
+                const double closing = len > 0.0 ? dot(delta_rel, correction) / len : 0.0;
+                double allowed = limit - closing;
+                if (!(allowed > 0.0))
+                    allowed = 0.0;
+                if (dist > allowed)
+                    error = allowed;
+            }
+            const double lambda = (error - 0.0) / (w + compliance);
 
             const Vec3 impulse = self_is_inc ? lambda * dir : (-lambda) * dir;
             term_pos = impulse * self.inv_mass;
@@ -826,17 +837,37 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
             const Vec3 p_other = Frame{frame_origin(other.pos, other.rot, other.com), other.rot} * anchor_other;
             const Vec3 difference = self_is_a ? p_other - p_self : p_self - p_other; // p_b - p_a
             const double dist = length(difference);
-            if (dist == 0.0)
-                continue; // coincident points: the reference's direction() would be NaN (K6); nothing to correct
-            const Vec3 dir = difference * (1.0 / dist);
-            const double w = generalized_inverse_mass(self, p_self, dir) + generalized_inverse_mass(other, p_other, dir);
-            const double lambda = (dist - jt.distance) / (w + compliance);
-            const Vec3 impulse = self_is_a ? lambda * dir : (-lambda) * dir;
-            dpos = dpos + impulse * self.inv_mass;
-            const Vec3 arm = p_self - (self.pos + self.com);
-            const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
-            drot = drot + (0.5 * spin) * self.rot;
-            ++count;
+            if (dist != 0.0) { // (coincident points: the reference's direction() would be NaN (K6); nothing to correct)
+                const Vec3 dir = difference * (1.0 / dist);
+                const double w = generalized_inverse_mass(self, p_self, dir) + generalized_inverse_mass(other, p_other, dir);
+                const double lambda = (dist - jt.distance) / (w + compliance);
+                const Vec3 impulse = self_is_a ? lambda * dir : (-lambda) * dir;
+                dpos = dpos + impulse * self.inv_mass;
+                const Vec3 arm = p_self - (self.pos + self.com);
+                const Quat spin = quat_sv(0.0, cross(self.inv_inertia * arm, impulse));
+                drot = drot + (0.5 * spin) * self.rot;
+                ++count;
+            }
+            if (jt.kind == XPBD_JOINT_HINGE) {
+                // the angular term (oracle: accumulate_hinge): the joint's axes, unit vectors in the object space of a and b,
+                // are kept aligned; evaluated per body, 3-vectors selected by role as above
+                const Vec3 axis_self = self_is_a ? Vec3{jt.axis_a[0], jt.axis_a[1], jt.axis_a[2]} : Vec3{jt.axis_b[0], jt.axis_b[1], jt.axis_b[2]};
+                const Vec3 axis_other = self_is_a ? Vec3{jt.axis_b[0], jt.axis_b[1], jt.axis_b[2]} : Vec3{jt.axis_a[0], jt.axis_a[1], jt.axis_a[2]};
+                const Vec3 w_self = self.rot * axis_self, w_other = other.rot * axis_other;
+                const Vec3 delta = self_is_a ? cross(w_self, w_other) : cross(w_other, w_self); // a_w x b_w
+                const double mag = length(delta);
+                if (mag != 0.0) {
+                    const Vec3 n = delta * (1.0 / mag);
+                    const Vec3 n_self = conjugate(self.rot) * n, n_other = conjugate(other.rot) * n;
+                    const double w_s = dot(self.inv_inertia * n_self, n_self), w_o = dot(other.inv_inertia * n_other, n_other);
+                    const double w = self_is_a ? w_s + w_o : w_o + w_s; // w_a + w_b (IEEE addition commutes; written out for the reader)
+                    const double lambda = mag / (w + compliance);
+                    const Vec3 turn = self_is_a ? lambda * n : (-lambda) * n;
+                    const Quat spin = quat_sv(0.0, self.inv_inertia * turn);
+                    drot = drot + (0.5 * spin) * self.rot;
+                    ++count;
+                }
+            }
         }
     }
 

@@ -1290,6 +1290,16 @@ int xpbd_multi_world_set_polytopes(xpbd_multi_world *mw, const xpbd_polytope *sh
     return XPBD_OK;
 }
 
+int xpbd_multi_world_set_max_depenetration_speed(xpbd_multi_world *mw, double speed)
+{
+    if (!mw)
+        return set_error(XPBD_E_INVALID, "xpbd_multi_world_set_max_depenetration_speed: NULL world");
+    for (Shard &s : mw->shards)
+        if (int rc = xpbd_world_set_max_depenetration_speed(s.world, speed))
+            return rc;
+    return XPBD_OK;
+}
+
 int xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, const uint32_t *shape_id, uint32_t first_global, uint32_t n_bodies,
                             uint32_t n_global, const xpbd_joint *joints, uint32_t n_joints)
 {

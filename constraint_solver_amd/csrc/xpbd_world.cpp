@@ -139,6 +139,7 @@ struct xpbd_world {
 
     // extension: contact pipeline (XPBD_MODE_CONTACTS)
     double contact_pad = 0.02;
+    double max_depenetration_speed = 0.0; // 0 = off (the reference's solver loop)
     uint32_t narrowphase = XPBD_NARROWPHASE_SAT;
     DeviceBuffer dyn_alt, cb_centers, cb_radius, cb_cell, cb_key, cb_maxr, cb_bucket_start, cb_bucket_cursor, cb_items,
         cb_nbr_off, cb_pair_first, cb_upper_start, cb_nbr, cb_nbr_pair, cb_pairs, cb_rec, cb_stat_rec,
@@ -218,6 +219,7 @@ struct xpbd_world {
         c.joints = n_joints ? jt_joints.as<xpbd::Joint>() : nullptr;
         c.joint_off = n_joints ? jt_off.as<uint32_t>() : nullptr;
         c.joint_list = n_joints ? jt_list.as<uint32_t>() : nullptr;
+        c.max_depenetration_speed = max_depenetration_speed;
         return c;
     }
 
@@ -1230,6 +1232,16 @@ int xpbd_world_set_joints(xpbd_world *w, const xpbd_joint *joints, uint32_t n_jo
                         j.body_b, w->n);
         if (!(j.distance >= 0.0) || !(j.distance <= 1.0e300))
             return fail(XPBD_E_INVALID, "xpbd_world_set_joints: joint %u has distance %g", k, j.distance);
+        if (j.kind != XPBD_JOINT_DISTANCE && j.kind != XPBD_JOINT_HINGE)
+            return fail(XPBD_E_INVALID, "xpbd_world_set_joints: joint %u has unknown kind %u", k, j.kind);
+        if (j.reserved != 0)
+            return fail(XPBD_E_INVALID, "xpbd_world_set_joints: joint %u: reserved must be 0", k);
+        if (j.kind == XPBD_JOINT_HINGE)
+            for (const double *axis : {j.axis_a, j.axis_b}) {
+                const double len2 = axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2];
+                if (!(len2 > 0.999 && len2 < 1.001))
+                    return fail(XPBD_E_INVALID, "xpbd_world_set_joints: hinge %u needs unit axes (|axis|^2 = %g)", k, len2);
+            }
         ++off[j.body_a + 1];
         ++off[j.body_b + 1];
     }
@@ -1356,6 +1368,14 @@ int xpbd_world_set_contact_pad(xpbd_world *w, double pad)
     if (!w || !(pad >= 0.0) || pad > 1.0e6)
         return fail(XPBD_E_INVALID, "xpbd_world_set_contact_pad: bad argument");
     w->contact_pad = pad;
+    return XPBD_OK;
+}
+
+int xpbd_world_set_max_depenetration_speed(xpbd_world *w, double speed)
+{
+    if (!w || !(speed >= 0.0) || speed > 1.0e300)
+        return fail(XPBD_E_INVALID, "xpbd_world_set_max_depenetration_speed: bad argument");
+    w->max_depenetration_speed = speed;
     return XPBD_OK;
 }
 

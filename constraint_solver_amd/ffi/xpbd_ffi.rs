@@ -90,6 +90,10 @@ pub struct XpbdJoint {
     pub anchor_a: [f64; 3],
     pub anchor_b: [f64; 3],
     pub distance: f64,
+    pub axis_a: [f64; 3], // XPBD_JOINT_HINGE: unit axes in the object space of a / b that the joint keeps aligned
+    pub axis_b: [f64; 3],
+    pub kind: u32,        // XPBD_JOINT_DISTANCE = 0, XPBD_JOINT_HINGE = 1
+    pub reserved: u32,
 }
 
 /// EXTENSION: result of the GJK + EPA narrowphase for one pair.
@@ -185,6 +189,8 @@ extern "C" {
     pub fn xpbd_world_build_neighbours(w: *mut XpbdWorld, dt: f64, n_entries_out: *mut u32) -> c_int;
     pub fn xpbd_world_download_neighbours(w: *mut XpbdWorld, offsets: *mut u32, neighbours: *mut u32, cap: u32) -> c_int;
     pub fn xpbd_world_set_joints(w: *mut XpbdWorld, joints: *const XpbdJoint, n_joints: u32) -> c_int;
+    pub fn xpbd_world_set_max_depenetration_speed(w: *mut XpbdWorld, speed: f64) -> c_int;
+    pub fn xpbd_multi_world_set_max_depenetration_speed(mw: *mut XpbdMultiWorld, speed: f64) -> c_int;
     pub fn xpbd_world_snapshot_positions(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *mut f64) -> c_int;
     pub fn xpbd_world_max_displacement2(w: *mut XpbdWorld, dev_indices: *const u32, n: u32, dev_snapshot: *const f64, dev_scale: *const f64, dev_max: *mut f64) -> c_int;
     // ---- extension: the multi-GPU world (one call per frame; the library owns streams, RCCL communicators and the halo plan) ----

@@ -253,6 +253,13 @@ int  xpbd_world_set_sat_schedule(xpbd_world *w, uint32_t schedule);
  * summation order -> derive.  Exact semantics: oracle/xpbd_pairs_oracle.h.  With no overlapping
  * spheres the result equals XPBD_MODE_PER_SUBSTEP bit for bit. */
 int  xpbd_world_set_contact_pad(xpbd_world *w, double pad);            /* default 0.02 (metres) */
+/* Optional limit on how fast a BODY-BODY contact may push its bodies apart: the length of a contact point's positional
+ * correction is limited to max(0, speed * h - what the incident point has already moved towards the reference surface in
+ * this substep) before lambda is formed, so the bodies part at `speed` instead of accelerating (0 = off, the default = the reference's solver loop,
+ * src/solver.rs:19-27, which resolves any penetration within ONE substep, i.e. at depth / h -- 120 m/s for 0.1 m at 20
+ * substeps per frame; light bodies squeezed between heavy ones leave a pile at that speed).  Ground contacts (the reference
+ * path) and joints are never limited.  Semantics: oracle/xpbd_pairs_oracle.h. */
+int  xpbd_world_set_max_depenetration_speed(xpbd_world *w, double speed);
 /* out = {neighbour pairs of the last step, touching pairs, manifold points}; the last two are
  * summed over substeps since the previous call and then reset. */
 int  xpbd_world_contact_stats(xpbd_world *w, uint64_t out[3]);
@@ -263,15 +270,27 @@ int  xpbd_world_download_neighbours(xpbd_world *w, uint32_t *offsets, uint32_t *
 /* Joints (EXTENSION; the reference has no joint type, only the unused `distance`
  * field of Constraint, src/constraint.rs:9).  A joint keeps |frame_b * anchor_b - frame_a * anchor_a|
  * at `distance` (anchors in object space, the space of the shape vertices).  distance = 0 is a ball
- * joint; a hinge is two ball joints on its axis.  Joints are projected in XPBD_MODE_CONTACTS together
+ * joint; XPBD_JOINT_HINGE adds an angular term (below).  Joints are projected in XPBD_MODE_CONTACTS together
  * with the body-body contacts (same Jacobi pass, after a body's contacts, ascending joint index).
  * Body indices refer to the bodies uploaded last; uploading bodies again clears the joints.
  * Only XPBD_MODE_CONTACTS projects joints: in the other modes a non-empty list is XPBD_E_INVALID. */
+#define XPBD_JOINT_DISTANCE 0u  /* positional term only (distance = 0: ball joint) */
+#define XPBD_JOINT_HINGE    1u  /* positional term + ANGULAR term: the unit axes axis_a / axis_b (object space of a / b) are kept
+                                 * aligned.  With a_w = rot_a * axis_a, b_w = rot_b * axis_b: delta = a_w x b_w, n = delta / |delta|,
+                                 * w = sum over both bodies of (I^-1 (q^-1 n)) . (q^-1 n) (the angular half of
+                                 * Constraint::inverse_resitance, src/constraint.rs:25-32), lambda = |delta| / (w + compliance);
+                                 * a turns by +lambda n, b by -lambda n, applied as Rigid::apply_impulse applies an angular
+                                 * displacement (src/rigid.rs:118-122).  It is a Jacobi entry of its own, after the joint's
+                                 * positional term.  A hinge = ball joint (distance 0) on the axis + this: one degree of freedom. */
 typedef struct xpbd_joint {
     uint32_t body_a, body_b;
     double   anchor_a[3];
     double   anchor_b[3];
     double   distance;
+    double   axis_a[3];   /* XPBD_JOINT_HINGE: unit vectors */
+    double   axis_b[3];
+    uint32_t kind;        /* XPBD_JOINT_* */
+    uint32_t reserved;    /* must be 0 */
 } xpbd_joint;
 int  xpbd_world_set_joints(xpbd_world *w, const xpbd_joint *joints, uint32_t n_joints);
 
@@ -365,6 +384,7 @@ void xpbd_multi_config_default(xpbd_multi_config *cfg);
 int  xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg);   /* collective over all ranks (RCCL) */
 void xpbd_multi_world_destroy(xpbd_multi_world *mw);
 int  xpbd_multi_world_set_polytopes(xpbd_multi_world *mw, const xpbd_polytope *shapes, uint32_t n_shapes);
+int  xpbd_multi_world_set_max_depenetration_speed(xpbd_multi_world *mw, double speed);   /* as xpbd_world_set_max_depenetration_speed */
 /* bodies: the slice of the caller's bodies this process HANDS OVER = global indices [first_global, first_global + n_bodies) of
  * n_global (rank r hands over the r-th of n_ranks near-equal contiguous ranges, the first n_global % n_ranks one body longer;
  * any order -- which rank ends up owning a body is decided by where the body is); joints: ALL joints of the world with GLOBAL

@@ -357,7 +357,7 @@ typedef struct {
 
 /* One manifold point seen from body `self_is_inc ? inc : ref`. */
 static void accumulate_point(int self_is_inc, const o_rigid *inc, const o_rigid *ref, o_frame inc_p1, o_frame inc_past,
-                             o_frame ref_p1, o_frame ref_past, o_vec3 p_inc, o_vec3 p_ref, double compliance,
+                             o_frame ref_p1, o_frame ref_past, o_vec3 p_inc, o_vec3 p_ref, double compliance, double limit,
                              pair_accum *acc)
 {
     o_vec3 correction = o_sub(p_ref, p_inc);
@@ -369,7 +369,19 @@ static void accumulate_point(int self_is_inc, const o_rigid *inc, const o_rigid 
     double distance = o_magnitude(difference);
     o_vec3 dir = o_scale(difference, 1.0 / distance);
     double w = generalized_inverse_mass(inc, c0, dir) + generalized_inverse_mass(ref, p_ref, dir);
-    double lambda = (distance - 0.0) / (w + compliance);
+    double error = distance;
+    if (limit > 0.0) { /* op_contacts_set_max_depenetration_speed: limit = speed * h, 0 when off */
+        /* what the incident point has ALREADY moved towards the reference surface in this substep (inertia, earlier
+         * corrections) counts against the allowance: the bodies part at the limit, they do not accelerate by it */
+        double len = o_magnitude(correction);
+        double closing = len > 0.0 ? o_dot(delta_rel, correction) / len : 0.0;
+        double allowed = limit - closing;
+        if (!(allowed > 0.0))
+            allowed = 0.0;
+        if (distance > allowed)
+            error = allowed;
+    }
+    double lambda = (error - 0.0) / (w + compliance);
 
     const o_rigid *self = self_is_inc ? inc : ref;
     o_vec3 point = self_is_inc ? c0 : p_ref;
@@ -396,9 +408,11 @@ struct op_frame {
     const op_joint *joints;
     uint32_t n_joints;
     int narrowphase; /* OP_NARROWPHASE_* */
+    double max_depenetration_speed; /* 0 = off */
 };
 
 void op_contacts_set_narrowphase(op_frame *f, int narrowphase) { f->narrowphase = narrowphase; }
+void op_contacts_set_max_depenetration_speed(op_frame *f, double speed) { f->max_depenetration_speed = speed; }
 
 /*
  * GJK + EPA result as a contact manifold (extension decision; nothing of this exists in the reference).
@@ -483,6 +497,32 @@ static void accumulate_joint(int self_is_a, const o_rigid *a, const o_rigid *b, 
     acc->count++;
 }
 
+/* The angular half of Constraint::inverse_resitance (src/constraint.rs:25-32) for a unit rotation axis n. */
+static double angular_inverse_mass(const o_rigid *body, o_vec3 n)
+{
+    o_vec3 local = o_qrot(o_qconj(body->rotation), n);
+    return o_dot(o_mat3_mulv(body->inverse_inertia, local), local);
+}
+
+/* The angular term of a hinge seen from body `self_is_a ? a : b` (op_joint in the header). */
+static void accumulate_hinge(int self_is_a, const o_rigid *a, const o_rigid *b, const op_joint *j, double compliance, pair_accum *acc)
+{
+    o_vec3 a_w = o_qrot(a->rotation, (o_vec3){ j->axis_a[0], j->axis_a[1], j->axis_a[2] });
+    o_vec3 b_w = o_qrot(b->rotation, (o_vec3){ j->axis_b[0], j->axis_b[1], j->axis_b[2] });
+    o_vec3 delta = o_cross(a_w, b_w);
+    double mag = o_magnitude(delta);
+    if (mag == 0.0)
+        return;
+    o_vec3 n = o_scale(delta, 1.0 / mag);
+    double w = angular_inverse_mass(a, n) + angular_inverse_mass(b, n);
+    double lambda = mag / (w + compliance);
+    const o_rigid *self = self_is_a ? a : b;
+    o_vec3 turn = self_is_a ? o_lscale(lambda, n) : o_lscale(-lambda, n);
+    o_quat spin = { 0.0, o_mat3_mulv(self->inverse_inertia, turn) };
+    acc->drot = o_qadd(acc->drot, o_qmul(o_qlscale(0.5, spin), self->rotation));
+    acc->count++;
+}
+
 op_frame *op_contacts_begin(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                             double dt, double pad)
 {
@@ -540,6 +580,7 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
     o_vec3 *past_pos = f->past_pos;
     o_rigid *next = f->next;
     const double compliance = 1e-6 / (h * h);
+    const double limit = f->max_depenetration_speed > 0.0 ? f->max_depenetration_speed * h : 0.0;
     {
         /* 1. integrate */
         for (uint32_t i = 0; i < n; i++) {
@@ -609,12 +650,15 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
                 uint32_t ref = ref_is_a ? a_body : b_body, inc = ref_is_a ? b_body : a_body;
                 for (uint32_t pt = 0; pt < m->n_points; pt++)
                     accumulate_point(inc == b, &bodies[inc], &bodies[ref], p1[inc], past[inc], p1[ref], past[ref],
-                                     m->p_inc[pt], m->p_ref[pt], compliance, &acc);
+                                     m->p_inc[pt], m->p_ref[pt], compliance, limit, &acc);
             }
             for (uint32_t jn = 0; jn < f->n_joints; jn++) { /* ascending joint index */
                 const op_joint *j = &f->joints[jn];
-                if (j->body_a == b || j->body_b == b)
+                if (j->body_a == b || j->body_b == b) {
                     accumulate_joint(j->body_a == b, &bodies[j->body_a], &bodies[j->body_b], j, compliance, &acc);
+                    if (j->kind == OP_JOINT_HINGE)
+                        accumulate_hinge(j->body_a == b, &bodies[j->body_a], &bodies[j->body_b], j, compliance, &acc);
+                }
             }
             next[b] = bodies[b];
             if (acc.count) {

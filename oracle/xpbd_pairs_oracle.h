@@ -104,13 +104,32 @@ void op_contacts_end(op_frame *f);
  * contacts = (p_a, p_b), lambda = (|p_b - p_a| - distance) / (w_a + w_b + compliance), +lambda*dir on
  * a at p_a, -lambda*dir on b at p_b.  A joint whose points coincide exactly is skipped (the
  * reference's direction() would be NaN, cf. K6). */
+/* kind OP_JOINT_HINGE adds an ANGULAR term after the positional one (its own entry in the Jacobi average): the unit axes
+ * axis_a / axis_b (object space of a / b) are kept aligned.  With a_w = rot_a * axis_a, b_w = rot_b * axis_b (poses after the
+ * ground contacts): delta = a_w x b_w, n = delta / |delta| (skipped when |delta| = 0: aligned, or exactly opposed),
+ * w = sum over the two bodies of (I^-1 (q^-1 n)) . (q^-1 n)  -- the angular half of Constraint::inverse_resitance,
+ * src/constraint.rs:25-32 --, lambda = |delta| / (w + compliance); body a turns by +lambda n, body b by -lambda n, applied as
+ * Rigid::apply_impulse applies an angular displacement (src/rigid.rs:118-122): rotation += (0.5 * Quat(0, I^-1 (lambda n))) * rotation.
+ * A hinge = a ball joint (distance 0) at a point of the axis + this term: one rotational degree of freedom left. */
+#define OP_JOINT_DISTANCE 0u
+#define OP_JOINT_HINGE    1u
 typedef struct {
     uint32_t body_a, body_b;
     double anchor_a[3], anchor_b[3];
     double distance;
+    double axis_a[3], axis_b[3]; /* OP_JOINT_HINGE only */
+    uint32_t kind, reserved;
 } op_joint;
 /* Must be called between begin and the first substep; `joints` must outlive the frame. */
 void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_joints);
+
+/* Optional limit on how fast a BODY-BODY contact may push its bodies apart (extension knob; 0 = off = the reference's solver
+ * loop, src/solver.rs:19-27, which resolves any penetration within one substep, i.e. at depth / h): the length of a contact
+ * point's positional correction (the `current_distance` of its constraint, friction part included) is limited to
+ * max(0, speed * h - closing), closing = what the incident point has already moved towards the reference surface in this
+ * substep (delta_rel . correction / |correction|), before lambda is formed: the bodies part at `speed`, they do not
+ * accelerate by it.  Ground contacts (the reference path) and joints are never limited. */
+void op_contacts_set_max_depenetration_speed(op_frame *f, double speed);
 
 /* Narrowphase of step 2: the SAT above (default) or GJK + EPA (xpbd_gjk_oracle.h), which yields ONE contact
  * point per touching pair (reference body A, incident body B; a degenerate query yields no contact). */

@@ -263,7 +263,8 @@ def broadphase(bodies, shape_id, polys, dt, pad):
 
 class Joint(C.Structure):
     _fields_ = [("body_a", C.c_uint32), ("body_b", C.c_uint32), ("anchor_a", C.c_double * 3), ("anchor_b", C.c_double * 3),
-                ("distance", C.c_double)]
+                ("distance", C.c_double), ("axis_a", C.c_double * 3), ("axis_b", C.c_double * 3), ("kind", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 def _frames_api():
@@ -282,7 +283,7 @@ def _frames_api():
     return L
 
 
-def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, narrowphase=0, stats=None):
+def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, narrowphase=0, stats=None, max_depenetration_speed=0.0):
     """One frame of op_contacts_* with joints (numpy records with the layout of `Joint`); narrowphase 1 = GJK + EPA.
     stats: optional ContactStats that the substeps add their touching pairs and manifold points to."""
     L = _frames_api()
@@ -295,6 +296,8 @@ def contacts_step_joints(bodies, shape_id, polys, joints, dt, substeps, pad, nar
     L.op_contacts_attach_joints(f, j.ctypes.data if j.size else None, j.size)
     L.op_contacts_set_narrowphase.restype, L.op_contacts_set_narrowphase.argtypes = None, [C.c_void_p, C.c_int]
     L.op_contacts_set_narrowphase(f, narrowphase)
+    L.op_contacts_set_max_depenetration_speed.restype, L.op_contacts_set_max_depenetration_speed.argtypes = None, [C.c_void_p, C.c_double]
+    L.op_contacts_set_max_depenetration_speed(f, max_depenetration_speed)
     for _ in range(substeps):
         L.op_contacts_substep(f, b.ctypes.data, dt / substeps, None, C.byref(stats) if stats is not None else None)
     L.op_contacts_end(f)

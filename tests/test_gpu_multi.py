@@ -209,6 +209,41 @@ def test_the_library_cuts_the_shards_whatever_the_callers_numbering(n_ranks):
     assert np.mean(results["shuffled"][1] == results["ordered"][1][perm]) > 0.97
 
 
+def test_sharded_world_with_hinges_across_shards_and_the_depenetration_limit():
+    """XPBD_JOINT_HINGE joints whose bodies live on different shards and xpbd_multi_world_set_max_depenetration_speed: the
+    sharded world equals the single one bit for bit (the angular term reads the partner's rotation from its ghost)."""
+    kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 96, 6, 25
+    bodies, sid = line_scene(capi, kind, n, 11, 1.3)
+    joints = chain_joints(capi, n, every=1, distance=1.3, limit=n // 2)
+    with capi.MultiWorld(3, devices=[0] * 3, transport=capi.TRANSPORT_LOCAL, halo_margin=0.75) as mw:   # who will own what?
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.upload(bodies, sid, 0, n)
+        owner = mw.owners()
+    hinges = (np.arange(len(joints)) % 4 == 3) | (owner[joints["body_a"]] != owner[joints["body_b"]])   # ... every joint across a cut
+    joints["kind"][hinges], joints["distance"][hinges] = capi.JOINT_HINGE, 0.0
+    joints["anchor_a"][hinges], joints["anchor_b"][hinges] = [1.15, 0.5, 0.5], [-0.15, 0.5, 0.5]
+    joints["axis_a"][hinges] = joints["axis_b"][hinges] = [0.0, 1.0, 0.0]
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.set_max_depenetration_speed(2.0)
+        w.upload(bodies, sid)
+        w.set_joints(joints)
+        for _ in range(frames):
+            w.step(DT, substeps)
+        one = w.download()
+    with capi.MultiWorld(3, devices=[0] * 3, transport=capi.TRANSPORT_LOCAL, halo_margin=0.75, auto_replan=True) as mw:
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.set_max_depenetration_speed(2.0)
+        mw.upload(bodies, sid, 0, n, joints)
+        owner = mw.owners()
+        for _ in range(frames):
+            mw.step(DT, substeps)
+        got = mw.download()
+    crossing = owner[joints["body_a"]] != owner[joints["body_b"]]
+    assert (crossing & hinges).any()
+    assert not np.isnan(one).any() and bits_equal(got, one)
+
+
 def test_rccl_transport_with_a_one_rank_communicator():
     """RCCL refuses two ranks on one device, so the collective path is exercised with one rank: unique id, communicator,
     the per-frame displacement all-gather and the per-substep halo all-gather run through ncclAllGather."""

@@ -738,3 +738,59 @@ def test_reference_edge_axes_separation_on_the_device_matches_the_oracle(kind, n
     assert (got["separation"] > 0).any() and (got["separation"] < 0).any()
     both_aligned = (pairs[:, 0] < 20) & (pairs[:, 1] < 20)          # pairs of axis-aligned bodies: most of their axes are NaN
     assert both_aligned.sum() > 10
+
+
+def hinged_chain(n, every=3):
+    """halo_common.chain_joints with every 4th joint a HINGE (XPBD_JOINT_HINGE: ball joint + angular term about z)."""
+    import halo_common as hc
+    joints = hc.chain_joints(capi, n, every=every)
+    hinges = np.arange(len(joints)) % 4 == 3
+    joints["kind"][hinges] = capi.JOINT_HINGE
+    joints["distance"][hinges] = 0.0
+    joints["anchor_a"][hinges] = [1.25, 0.5, 0.5]                    # a common point between the two boxes (1.5 m apart at rest)
+    joints["anchor_b"][hinges] = [-0.25, 0.5, 0.5]
+    joints["axis_a"][hinges] = joints["axis_b"][hinges] = [0.0, 0.0, 1.0]
+    return joints
+
+
+@pytest.mark.parametrize("speed", [0.0, 3.0])
+def test_hinges_and_the_depenetration_limit_match_the_oracle(speed):
+    """The angular joint term (hinges in the chains) and xpbd_world_set_max_depenetration_speed, in a pile with deep initial
+    overlaps (where the limit matters), bit for bit like the oracle; both change the result."""
+    kind, n, frames, substeps = capi.SCENE_BOXES_DROP, 160, 20, 10
+    bodies, sid = pile(kind, n, 6, 4.0, 6.0)
+    joints = hinged_chain(n)
+    assert (joints["kind"] == capi.JOINT_HINGE).sum() > 10
+    polys = ob.polytopes_array([("cube", 1.0)])
+    want = bodies
+    for _ in range(frames):
+        want = ob.contacts_step_joints(want, sid, polys, joints, DT, substeps, 0.02, max_depenetration_speed=speed)
+    with capi.World(mode=capi.MODE_CONTACTS) as w:
+        w.set_polytopes(capi.scene_polytopes(kind))
+        w.set_max_depenetration_speed(speed)
+        w.upload(bodies, sid)
+        w.set_joints(joints)
+        for _ in range(frames):
+            w.step(DT, substeps)
+        got = w.download()
+        assert not np.isnan(got).any() and bits_equal(got, want)
+        plain = joints.copy()                                        # the same joints without the angular term
+        plain["kind"] = capi.JOINT_DISTANCE
+        w.upload(bodies, sid)
+        w.set_joints(plain)
+        for _ in range(frames):
+            w.step(DT, substeps)
+        assert not bits_equal(w.download(), want)
+        bad = joints[:1].copy()
+        bad["kind"], bad["axis_a"] = capi.JOINT_HINGE, [0.0, 0.0, 2.0]
+        with pytest.raises(capi.XpbdError):
+            w.set_joints(bad)                                        # axes must be unit vectors
+        bad["kind"] = 7
+        with pytest.raises(capi.XpbdError):
+            w.set_joints(bad)
+    if speed:                                                        # the overlaps of this pile are resolved more gently
+        free = bodies
+        for _ in range(frames):
+            free = ob.contacts_step_joints(free, sid, polys, joints, DT, substeps, 0.02)
+        assert not bits_equal(free, want)
+        assert np.linalg.norm(want[:, 22:25], axis=1).max() < np.linalg.norm(free[:, 22:25], axis=1).max()
