@@ -125,7 +125,8 @@ def cpu_baseline_pinned(state, shape_id, verts, offsets, substeps, budget_s=4.0,
     return out
 
 
-def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphase, joints, pick, what, budget_s=4.0, repeats=3):
+def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphase, joints, pick, what, budget_s=4.0, repeats=3,
+                          depenetration=0.0):
     """op_contacts_* of the oracle (body-body contact EXTENSION, single thread) on the bodies `pick` (ascending indices)
     of the GPU's pre-rolled state; joints with both bodies inside the sample are kept."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -141,7 +142,7 @@ def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphas
     joints = joints[inside].copy()
     joints["body_a"], joints["body_b"] = np.searchsorted(pick, joints["body_a"]), np.searchsorted(pick, joints["body_b"])
     t0 = time.perf_counter()
-    ob.contacts_step_joints(start, sid, polys, joints, FRAME_TIME, substeps, pad, narrowphase=narrowphase)
+    ob.contacts_step_joints(start, sid, polys, joints, FRAME_TIME, substeps, pad, narrowphase=narrowphase, max_depenetration_speed=depenetration)
     one = time.perf_counter() - t0
     frames = int(max(1, min(50, budget_s / max(one, 1e-6))))
 
@@ -149,7 +150,8 @@ def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphas
         bodies = start
         t0 = time.perf_counter()
         for _ in range(frames):
-            bodies = ob.contacts_step_joints(bodies, sid, polys, joints, FRAME_TIME, substeps, pad, narrowphase=narrowphase)
+            bodies = ob.contacts_step_joints(bodies, sid, polys, joints, FRAME_TIME, substeps, pad, narrowphase=narrowphase,
+                                             max_depenetration_speed=depenetration)
         return time.perf_counter() - t0
 
     value, rates = median_rate(run, n * substeps * frames, repeats)
@@ -159,15 +161,42 @@ def cpu_baseline_contacts(state, shape_id, poly_names, substeps, pad, narrowphas
                       "reference has no body-body contacts), 1 thread" % (n, what, len(joints), frames, substeps, repeats)}
 
 
-def chain_joints(capi, np, n_joints, count, pitch, grid_w):
-    """BASELINE configs[4] (extension): chains of 5 bodies, 4 distance joints each, centre to centre at the pitch.
-    A chain that would wrap around the end of a grid row loses the joint across the wrap."""
+def qrot(np, q, v):
+    """cgmath's q * v for arrays of quaternions (s, x, y, z) and vectors."""
+    s, u = q[:, :1], q[:, 1:]
+    t = np.cross(u, v) + v * s
+    return np.cross(u, t) * 2 + v
+
+
+def chain_joints(capi, np, n_joints, count, pitch, grid_w, state=None, first=0):
+    """BASELINE configs[4] (extension): chains of 5 bodies with 4 joints each, "every 4th a hinge":
+    three distance joints centre to centre at the pitch, the fourth an XPBD_JOINT_HINGE (ball joint + angular term) at the
+    point midway between the two bodies about the vertical.  A chain that would wrap around the end of a grid row loses
+    the joint across the wrap.  state: the (count, 38) bodies [first, first + count) at t = 0 -- a hinge's anchors and axes
+    live in the object space of its (randomly turned) bodies, so they are taken from the initial poses: every hinge
+    starts exactly satisfied.  Without `state` (sharded runs, which do not hold all bodies) all joints are distance joints."""
     k = np.arange(n_joints)
     a = (k // 4) * 5 + (k % 4)
-    a = a[(a + 1 < count) & (a // grid_w == (a + 1) // grid_w)]
+    keep = (a + 1 < count) & (a // grid_w == (a + 1) // grid_w)
+    a, k = a[keep], k[keep]
     joints = np.zeros(len(a), dtype=capi.JOINT_DTYPE)
     joints["body_a"], joints["body_b"] = a, a + 1
     joints["anchor_a"], joints["anchor_b"], joints["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], pitch
+    if state is not None:
+        h = np.nonzero(k % 4 == 3)[0]
+        ba, bb = state[a[h] - first], state[a[h] + 1 - first]
+
+        def pose(b):                                     # Rigid::frame (src/rigid.rs:75-80): origin, rotation; world centre of mass
+            com, q = b[:, 28:31], b[:, 34:38]
+            return (b[:, 31:34] + com) + qrot(np, q, -com), q, b[:, 31:34] + com
+        oa, qa, ca = pose(ba)
+        ob_, qb, cb = pose(bb)
+        mid = 0.5 * (ca + cb)
+        conj = lambda q: q * np.array([1.0, -1.0, -1.0, -1.0])
+        up = np.tile([0.0, 0.0, 1.0], (len(h), 1))
+        joints["kind"][h], joints["distance"][h] = capi.JOINT_HINGE, 0.0
+        joints["anchor_a"][h], joints["anchor_b"][h] = qrot(np, conj(qa), mid - oa), qrot(np, conj(qb), mid - ob_)
+        joints["axis_a"][h], joints["axis_b"][h] = qrot(np, conj(qa), up), qrot(np, conj(qb), up)
     return joints
 
 
@@ -218,7 +247,7 @@ def sample_of(np, total, layers, sample):
 
 
 def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pitch, rank, local_rank, world_size, steps, warmup,
-                 with_cpu, layers=0, name=None):
+                 with_cpu, layers=0, name=None, depenetration=0.0):
     """One contact-pipeline measurement on a world of its own: pre-roll, warm-up, K timed frames.  Returns the result
     object (rank 0) -- value, roofline of a whole substep, cpu_baseline -- or None."""
     kind = getattr(capi, SCENE_KIND[scene])
@@ -227,17 +256,18 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
     preroll = PREROLL_PILE if layers else PREROLL[scene]
     if world_size > 1 or args.local_shards:
         return run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank,
-                                    local_rank, world_size, steps, warmup, local_shards=args.local_shards)
+                                    local_rank, world_size, steps, warmup, local_shards=args.local_shards, depenetration=depenetration)
     count = total
     state, shape_id = contacts_scene(capi, args, kind, total, pitch, layers)
     world = capi.World(device=local_rank, mode=capi.MODE_CONTACTS)
     world.set_polytopes(capi.scene_polytopes(kind))
     world.set_contact_pad(pad)
     world.set_narrowphase(capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT)
+    world.set_max_depenetration_speed(depenetration)
     world.set_sat_schedule({"auto": capi.SAT_SCHEDULE_AUTO, "one-pass": capi.SAT_SCHEDULE_ONE_PASS,
                             "two-pass": capi.SAT_SCHEDULE_TWO_PASS}[args.sat_schedule])
     world.upload(state, shape_id)
-    joints = chain_joints(capi, np, joints_n, count, pitch, scene_grid_width(capi, kind, total, total)) if joints_n else None
+    joints = chain_joints(capi, np, joints_n, count, pitch, scene_grid_width(capi, kind, total, total), state=state) if joints_n else None
     if joints is not None:
         world.set_joints(joints)
     stream = torch.cuda.current_stream()
@@ -278,6 +308,8 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
             "config": {"workload": contacts_workload(scene, bodies, args.substeps, narrowphase, joints_n, pitch, layers),
                        "bodies_per_gpu": bodies, "substeps": args.substeps, "scene": scene, "pitch": pitch, "layers": layers,
                        "narrowphase": narrowphase, "joints": 0 if joints is None else int(len(joints)),
+                       "hinges": 0 if joints is None else int((joints["kind"] == capi.JOINT_HINGE).sum()),
+                       "max_depenetration_speed": depenetration,
                        "neighbour_pairs": pairs, "touching_pairs_per_substep": touching_ps,
                        "manifold_points_per_substep": points_ps,
                        "ground_contacts_per_body_at_start": ground_start,
@@ -298,13 +330,13 @@ def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pi
         if with_cpu:
             pick, what = sample_of(np, total, layers, 4096)
             result["cpu_baseline"] = cpu_baseline_contacts(start_state, shape_id, POLY_NAMES["mixed" in scene], args.substeps, pad,
-                                                           1 if narrowphase == "gjk" else 0, joints, pick, what)
+                                                           1 if narrowphase == "gjk" else 0, joints, pick, what, depenetration=depenetration)
     world.close()
     return result
 
 
 def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank, local_rank,
-                         world_size, steps, warmup, local_shards=0):
+                         world_size, steps, warmup, local_shards=0, depenetration=0.0):
     """EXTENSION, N > 1: body-body contacts through the NATIVE multi-GPU world (xpbd_multi_world_*, csrc/xpbd_multi.cpp):
     every rank hands over its index slice of the scene (generating ONLY those bodies); the library cuts the shards -- slabs
     of space across the world's longest axis, near-equal body counts, re-balanced at every re-plan -- moves each body to
@@ -330,7 +362,23 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
         parts.append(part)
         sids.append(sid)
     state, shape_id = np.concatenate(parts), np.concatenate(sids)
-    joints = chain_joints(capi, np, joints_n * n_ranks, total, pitch, scene_grid_width(capi, kind, bodies, total)) if joints_n else None
+    joints = None
+    if joints_n:
+        # ALL joints of the world on every rank (the ABI asks for that).  A hinge's anchors come from its two bodies' initial
+        # poses, and the scene is a pure function of (seed, index): generate it in chunks of whole chains, keep only the joints.
+        grid_w, chunk, parts_j = scene_grid_width(capi, kind, bodies, total), 5 * 65536, []
+        for c0 in range(0, total, chunk):
+            cn = min(chunk, total - c0)
+            part, _ = capi.scene_generate(kind, args.seed, total, first=c0, count=cn, grid_w=grid_w)
+            if pitch != 2.0:
+                part[:, 31:33] *= pitch / 2.0
+            j = chain_joints(capi, np, (cn // 5) * 4, cn, pitch, grid_w, state=part)      # (chunk-local indices; c0 is a multiple of 5)
+            keep = (j["body_a"] + c0) // grid_w == (j["body_b"] + c0) // grid_w             # the row test, in global indices
+            j = j[keep]
+            j["body_a"] += c0
+            j["body_b"] += c0
+            parts_j.append(j)
+        joints = np.concatenate(parts_j)[: joints_n * n_ranks]
     if local_shards:
         world = capi.MultiWorld(n_ranks, devices=[local_rank] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=0.5,
                                 narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT, auto_replan=True)
@@ -343,6 +391,7 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
                                 auto_replan=True)
         transport = "ncclAllGather, RCCL bound from %s" % capi.comm_library()
     world.set_polytopes(capi.scene_polytopes(kind))
+    world.set_max_depenetration_speed(depenetration)
     world.upload(state, shape_id, first_global, total, joints)
     for _ in range(preroll + warmup):
         world.step(FRAME_TIME, args.substeps)
@@ -360,6 +409,7 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
             "steps": steps, "warmup": warmup, "preroll_frames": preroll,
             "config": {"workload": contacts_workload(scene, bodies, args.substeps, narrowphase, joints_n, pitch, layers),
                        "bodies_per_gpu": bodies, "bodies_total": total, "substeps": args.substeps, "scene": scene,
+                       "max_depenetration_speed": depenetration,
                        "sharding": "shards cut by the library from the spatial-hash cell order (slabs across the world's longest axis, "
                                    "near-equal body counts, re-balanced at re-plans), owned + ghost bodies per rank; halo plan, end-of-frame "
                                    "halo-validity check (a violating frame is undone and re-run) and one all-gather per substep inside "
@@ -446,6 +496,8 @@ def main():
                          "exchanged by the in-process transport (bodies per shard = --bodies)")
     ap.add_argument("--pitch", type=float, default=2.0,
                     help="grid pitch of the scene in metres (generator default 2.0); < 2 packs bodies so that they collide")
+    ap.add_argument("--max-depenetration-speed", type=float, default=0.0,
+                    help="contacts mode: xpbd_world_set_max_depenetration_speed in m/s (0 = off = the reference's solver loop)")
     ap.add_argument("--layers", type=int, default=0,
                     help="contacts mode: drop the scene's bodies as a pile of this many grid layers (capi.scene_pile)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -499,14 +551,12 @@ def main():
         "stacks_262144_sat": dict(scene="stacks", bodies=262144, narrowphase="sat", joints_n=0, pitch=2.0),
         "stacks_262144_gjk_epa": dict(scene="stacks", bodies=262144, narrowphase="gjk", joints_n=0, pitch=2.0),
         "boxes_pile_262144_sat": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=0, pitch=1.8, layers=4),
-        "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4),
-        "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4),
+        # (the mixed piles with xpbd_world_set_max_depenetration_speed = 3 m/s: without a limit a light tetrahedron -- 1/48 of a
+        #  cube's mass -- squeezed between heavy bodies leaves the pile at > 100 m/s, frame after frame, and the pile never rests)
+        "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4, depenetration=3.0),
+        "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4, depenetration=3.0),
         "boxes_262144_joints_65536": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=65536, pitch=2.0),
     }
-    if world_size > 1:
-        # the mixed piles keep shedding light tetrahedra at > 100 m/s ("Scenes"): several metres per frame,
-        # beyond any halo margin worth having -- the sharded world would (rightly) refuse them with XPBD_E_HALO
-        sub_runs = {k: v for k, v in sub_runs.items() if not k.startswith("mixed_pile")}
     if args.contacts_child:
         # N > 1: the sub-results of the default line, in a process group of their own (see contacts_in_child_processes)
         subs = {}
@@ -536,7 +586,7 @@ def main():
 
     if args.mode == "contacts":
         r = run_contacts(capi, np, torch, args, args.scene, args.bodies, args.narrowphase, args.joints, args.pitch, rank, local_rank,
-                         world_size, args.steps, args.warmup, with_cpu, layers=args.layers)
+                         world_size, args.steps, args.warmup, with_cpu, layers=args.layers, depenetration=args.max_depenetration_speed)
         result = None
         if rank == 0:
             result = {"metric": METRIC, "value": r["value"], "unit": UNIT, "n_gpus": world_size, "steps": args.steps,
