@@ -247,13 +247,13 @@ def sample_of(np, total, layers, sample):
 
 
 def run_contacts(capi, np, torch, args, scene, bodies, narrowphase, joints_n, pitch, rank, local_rank, world_size, steps, warmup,
-                 with_cpu, layers=0, name=None, depenetration=0.0):
+                 with_cpu, layers=0, name=None, depenetration=0.0, preroll=None):
     """One contact-pipeline measurement on a world of its own: pre-roll, warm-up, K timed frames.  Returns the result
     object (rank 0) -- value, roofline of a whole substep, cpu_baseline -- or None."""
     kind = getattr(capi, SCENE_KIND[scene])
     total = bodies * world_size
     pad = 0.02
-    preroll = PREROLL_PILE if layers else PREROLL[scene]
+    preroll = preroll or (PREROLL_PILE if layers else PREROLL[scene])
     if world_size > 1 or args.local_shards:
         return run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase, joints_n, pitch, layers, preroll, rank,
                                     local_rank, world_size, steps, warmup, local_shards=args.local_shards, depenetration=depenetration)
@@ -552,9 +552,12 @@ def main():
         "stacks_262144_gjk_epa": dict(scene="stacks", bodies=262144, narrowphase="gjk", joints_n=0, pitch=2.0),
         "boxes_pile_262144_sat": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=0, pitch=1.8, layers=4),
         # (the mixed piles with xpbd_world_set_max_depenetration_speed = 3 m/s: without a limit a light tetrahedron -- 1/48 of a
-        #  cube's mass -- squeezed between heavy bodies leaves the pile at > 100 m/s, frame after frame, and the pile never rests)
-        "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4, depenetration=3.0),
-        "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4, depenetration=3.0),
+        #  cube's mass -- squeezed between heavy bodies leaves the pile at > 100 m/s, frame after frame, and the pile never rests;
+        #  with it nobody moves faster than 5 m/s after 210 frames, hence the longer pre-roll: profiles/r03_d_mixed_pile_speed_census.json)
+        "mixed_pile_65536_gjk_epa": dict(scene="mixed-drop", bodies=65536, narrowphase="gjk", joints_n=0, pitch=1.4, layers=4, depenetration=3.0,
+                                         preroll=240),
+        "mixed_pile_65536_sat": dict(scene="mixed-drop", bodies=65536, narrowphase="sat", joints_n=0, pitch=1.4, layers=4, depenetration=3.0,
+                                     preroll=240),
         "boxes_262144_joints_65536": dict(scene="boxes-drop", bodies=262144, narrowphase="sat", joints_n=65536, pitch=2.0),
     }
     if args.contacts_child:

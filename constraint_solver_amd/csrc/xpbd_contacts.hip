@@ -543,7 +543,8 @@ __global__ void __launch_bounds__(kBlock) k_integrate_ground(BodyArrays b, Shape
     const double compliance = 1e-6 / (h * h);
 
     const SubstepFrames f = integrate_body(d, s, h);
-    const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
+    const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0,
+                                       c.max_depenetration_speed > 0.0 ? c.max_depenetration_speed * h : 0.0);
 
     // the pose after the ground contacts lives in the record only: the pair solve (the one reader) takes it from there and
     // rewrites the whole SoA state (velocities come from derive)
@@ -968,7 +969,8 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         const uint32_t v0 = lds_off[sid];
         const double compliance = 1e-6 / (h * h);
         const SubstepFrames f = integrate_body(d, s, h);
-        const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0);
+        const uint32_t mask = solve_ground(d, s, f, compliance, lds + 3 * v0, lds_off[sid + 1] - v0,
+                                       c.max_depenetration_speed > 0.0 ? c.max_depenetration_speed * h : 0.0);
         if (sub == 0) {
             // everything the next kernel needs of this body is its record: no SoA state is written between the substeps of
             // a step call (the last substep's k_pair_solve_derive writes all 13 dynamic fields)

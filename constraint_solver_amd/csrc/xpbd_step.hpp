@@ -119,9 +119,12 @@ __device__ __forceinline__ uint32_t ground_mask(const Frame &cur, const double *
 // order).  Lane-compacting the contact work this way makes a wave run the expensive body max-over-lanes(contact
 // count) times instead of once per shape vertex with most lanes masked off.  Recomputing x for the chosen vertex
 // repeats the pass-1 arithmetic exactly, so the bits match.  (pos, rot) is the live pose the impulses act on.
+// `limit` (> 0 only in XPBD_MODE_CONTACTS with xpbd_world_set_max_depenetration_speed; the pinned path passes the literal 0
+// and compiles to the reference's arithmetic alone): the length of a ground constraint's correction is limited to
+// max(0, limit - what the vertex has already moved towards its target in this substep), limit = speed * h.
 __device__ __forceinline__ void solve_masked(Vec3 &pos, Quat &rot, double inv_mass, const Mat3 &inv_inertia, const Vec3 &com,
                                              const Frame &cur, const Frame &past, double compliance, const double *verts,
-                                             uint32_t mask)
+                                             uint32_t mask, double limit = 0.0)
 {
     const Frame cur_inv = inverse(cur); // src/frame.rs:30-37, shared by every penetrating vertex
     for (uint32_t todo = mask; todo != 0; todo &= todo - 1) {
@@ -145,7 +148,17 @@ __device__ __forceinline__ void solve_masked(Vec3 &pos, Quat &rot, double inv_ma
         // inverse_resitance, src/constraint.rs:25-32 (reads the LIVE pose)
         const Vec3 angular_impulse = conjugate(rot) * cross(c0 - (pos + com), direction);
         const double w = inv_mass + dot(inv_inertia * angular_impulse, angular_impulse);
-        const double lagrange = (current_distance - 0.0) / (w + compliance);
+        double error = current_distance;
+        if (limit > 0.0) {
+            const double len = length(correction);
+            const double closing = len > 0.0 ? dot(delta, correction) / len : 0.0;
+            double allowed = limit - closing;
+            if (!(allowed > 0.0))
+                allowed = 0.0;
+            if (current_distance > allowed)
+                error = allowed;
+        }
+        const double lagrange = (error - 0.0) / (w + compliance);
         // act -> apply_impulse, src/constraint.rs:34-37, src/rigid.rs:113-123
         const Vec3 impulse = lagrange * direction;
         pos = pos + impulse * inv_mass;
@@ -158,10 +171,10 @@ __device__ __forceinline__ void solve_masked(Vec3 &pos, Quat &rot, double inv_ma
 
 // Both passes for the lane's own body.  Returns the contact mask.
 __device__ __forceinline__ uint32_t solve_ground(BodyDynamic &d, const BodyStatic &s, const SubstepFrames &f,
-                                                 double compliance, const double *verts, uint32_t n_verts)
+                                                 double compliance, const double *verts, uint32_t n_verts, double limit = 0.0)
 {
     const uint32_t mask = ground_mask(f.cur, verts, n_verts);
-    solve_masked(d.pos, d.rot, s.inv_mass, s.inv_inertia, s.com, f.cur, f.past, compliance, verts, mask);
+    solve_masked(d.pos, d.rot, s.inv_mass, s.inv_inertia, s.com, f.cur, f.past, compliance, verts, mask, limit);
     return mask;
 }
 

@@ -257,8 +257,9 @@ int  xpbd_world_set_contact_pad(xpbd_world *w, double pad);            /* defaul
  * correction is limited to max(0, speed * h - what the incident point has already moved towards the reference surface in
  * this substep) before lambda is formed, so the bodies part at `speed` instead of accelerating (0 = off, the default = the reference's solver loop,
  * src/solver.rs:19-27, which resolves any penetration within ONE substep, i.e. at depth / h -- 120 m/s for 0.1 m at 20
- * substeps per frame; light bodies squeezed between heavy ones leave a pile at that speed).  Ground contacts (the reference
- * path) and joints are never limited.  Semantics: oracle/xpbd_pairs_oracle.h. */
+ * substeps per frame; light bodies squeezed between heavy ones leave a pile at that speed).  With the knob on, the ground
+ * contacts of XPBD_MODE_CONTACTS are limited the same way; joints never are; XPBD_MODE_FUSED / _PER_SUBSTEP (the reference path)
+ * ignore it.  Semantics: oracle/xpbd_pairs_oracle.h. */
 int  xpbd_world_set_max_depenetration_speed(xpbd_world *w, double speed);
 /* out = {neighbour pairs of the last step, touching pairs, manifold points}; the last two are
  * summed over substeps since the previous call and then reset. */

@@ -523,6 +523,36 @@ static void accumulate_hinge(int self_is_a, const o_rigid *a, const o_rigid *b, 
     acc->count++;
 }
 
+/* solver::solve (src/solver.rs:19-27) over the ground constraints of one body with op_contacts_set_max_depenetration_speed
+ * on: the length of a constraint's correction is limited to max(0, limit - closing), closing = what the vertex has already
+ * moved towards its target in this substep (collision::ground's delta_position along its correction, src/collision.rs:22-24;
+ * taken from the body's pose BEFORE the first constraint acts, like the constraints themselves). */
+static void solve_ground_limited(o_rigid *rigid, o_frame past, const o_constraint *cs, uint32_t n, double dt, double limit)
+{
+    double compliance = 1e-6 / (dt * dt);
+    double closing[O_MAX_VERTS];
+    o_frame cur = o_rigid_frame(rigid);
+    for (uint32_t k = 0; k < n; k++) {
+        o_vec3 position = cs[k].contact0;
+        o_vec3 correction = o_sub((o_vec3){ position.x, position.y, 0.0 }, position);
+        o_vec3 delta = o_frame_delta(cur, past, position);
+        double len = o_magnitude(correction);
+        closing[k] = len > 0.0 ? o_dot(delta, correction) / len : 0.0;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        const o_constraint *c = &cs[k];
+        const o_rigid *ro[1] = { rigid };
+        o_rigid *rw[1] = { rigid };
+        double distance = o_constraint_current_distance(c);
+        double allowed = limit - closing[k];
+        if (!(allowed > 0.0))
+            allowed = 0.0;
+        double error = distance > allowed ? allowed : distance;
+        double lagrange_factor = (error - c->distance) / (o_constraint_inverse_resistance(c, ro) + compliance);
+        o_constraint_act(c, rw, lagrange_factor);
+    }
+}
+
 op_frame *op_contacts_begin(const o_rigid *bodies, const uint32_t *shape_id, uint32_t n, const o_polytope *shapes,
                             double dt, double pad)
 {
@@ -624,7 +654,10 @@ void op_contacts_substep(op_frame *f, o_rigid *bodies, double h, uint32_t *masks
             o_constraint cs[O_MAX_VERTS];
             uint32_t cv[O_MAX_VERTS];
             uint32_t nc = o_ground(&bodies[i], past[i], p->vertices, p->n_vertices, cs, cv);
-            o_solve(&bodies[i], cs, nc, h);
+            if (limit > 0.0)
+                solve_ground_limited(&bodies[i], past[i], cs, nc, h, limit);
+            else
+                o_solve(&bodies[i], cs, nc, h);
             if (masks_row) {
                 uint32_t mask = 0;
                 for (uint32_t c = 0; c < nc; c++)

@@ -128,7 +128,9 @@ void op_contacts_attach_joints(op_frame *f, const op_joint *joints, uint32_t n_j
  * point's positional correction (the `current_distance` of its constraint, friction part included) is limited to
  * max(0, speed * h - closing), closing = what the incident point has already moved towards the reference surface in this
  * substep (delta_rel . correction / |correction|), before lambda is formed: the bodies part at `speed`, they do not
- * accelerate by it.  Ground contacts (the reference path) and joints are never limited. */
+ * accelerate by it.  With the knob on, the ground contacts of the contact pipeline (step 3) are limited the same way -- a
+ * light body pressed into the plane z = 0 by a heavy one is otherwise shot out of the pile by the plane -- ; joints never are.
+ * With the knob off (the default) nothing changes anywhere. */
 void op_contacts_set_max_depenetration_speed(op_frame *f, double speed);
 
 /* Narrowphase of step 2: the SAT above (default) or GJK + EPA (xpbd_gjk_oracle.h), which yields ONE contact
