@@ -79,6 +79,7 @@ COMM_ID_BYTES = 128
 TRANSPORT_RCCL, TRANSPORT_LOCAL = 0, 1
 MULTI_AUTO_REPLAN = 1
 MULTI_PLAN_THROUGH_DEVICE = 2
+MULTI_SERIAL_ENQUEUE = 4
 
 
 class PolytopeDesc(C.Structure):
@@ -456,7 +457,7 @@ class MultiWorld:
     (EXTENSION; the caller is World::integrate, src/world.rs:34-43)."""
 
     def __init__(self, n_ranks, first_rank=0, devices=(0,), transport=TRANSPORT_RCCL, comm_id=None, pad=0.02, halo_margin=0.5,
-                 narrowphase=NARROWPHASE_SAT, auto_replan=False, plan_through_device=False):
+                 narrowphase=NARROWPHASE_SAT, auto_replan=False, plan_through_device=False, serial_enqueue=False):
         L = hip_lib()
         cfg = MultiConfig()
         L.xpbd_multi_config_default(C.byref(cfg))
@@ -464,7 +465,8 @@ class MultiWorld:
         self._comm_id = comm_id
         cfg.n_ranks, cfg.first_rank, cfg.n_local, cfg.devices = n_ranks, first_rank, len(devices), self._devices
         cfg.transport, cfg.comm_id = transport, comm_id
-        cfg.flags = (MULTI_AUTO_REPLAN if auto_replan else 0) | (MULTI_PLAN_THROUGH_DEVICE if plan_through_device else 0)
+        cfg.flags = (MULTI_AUTO_REPLAN if auto_replan else 0) | (MULTI_PLAN_THROUGH_DEVICE if plan_through_device else 0) \
+            | (MULTI_SERIAL_ENQUEUE if serial_enqueue else 0)
         cfg.contact_pad, cfg.halo_margin, cfg.narrowphase = pad, halo_margin, narrowphase
         self._h = C.c_void_p()
         _check(L.xpbd_multi_world_create(C.byref(self._h), C.byref(cfg)))

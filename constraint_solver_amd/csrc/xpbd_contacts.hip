@@ -627,10 +627,66 @@ __device__ __forceinline__ BodyStatic static_of(const BodyArrays &b, uint32_t i,
     return s;
 }
 
-// (past_pos: optional, the position before integrate -- only a body's own derive needs it)
-__device__ __forceinline__ PairBody load_pair_body(const ContactBuffers &c, uint32_t i, Vec3 *past_pos = nullptr)
+// The BodyRecords of a workgroup's OWN bodies, staged in LDS (the per-body kernels with one lane per body and no body list):
+// a body's neighbours are gathers of whole records -- 2 x 128-byte lines each -- and in an index-coherent scene (box stacks: a
+// column is 16 consecutive bodies) most of them are bodies of the same workgroup, whose records the workgroup has loaded once
+// already.  PMC on `stacks` (profiles/r02_c): 373 MB read per launch for ~160 MB of distinct data, the kernel at the gather
+// rate of the memory system (5.3 TB/s of lines).  Word k of the record of the workgroup's body t sits at words[k * kBlock + t]:
+// consecutive lanes read consecutive 16-byte words (no bank conflicts).  Same values from another place: same bits.
+#ifndef XPBD_PAIR_SOLVE_STAGE_RECORDS
+#define XPBD_PAIR_SOLVE_STAGE_RECORDS 0 // measured and rejected, see DESIGN.md 8 (the fetched bytes of the kernel fall by 29 % on box stacks, its time does not)
+#endif
+struct RecordStage {
+    const double2 *words = nullptr; // LDS; null = not staged
+    uint32_t first = 0, count = 0;  // bodies [first, first + count) are staged
+};
+
+__device__ __forceinline__ BodyRecord load_record_staged(const double *__restrict__ rec, uint32_t i, const RecordStage &stage)
 {
-    const BodyRecord r = load_record(c.rec, i);         // two cache lines
+    const uint32_t t = i - stage.first;
+    if (stage.words && t < stage.count) {
+        double2 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            v[k] = stage.words[k * kBlock + t];
+        BodyRecord o;
+        o.p1 = Frame{Vec3{v[0].x, v[0].y, v[1].x}, Quat{v[1].y, v[2].x, v[2].y, v[3].x}};
+        o.past = Frame{Vec3{v[3].y, v[4].x, v[4].y}, Quat{v[5].x, v[5].y, v[6].x, v[6].y}};
+        o.pos = Vec3{v[7].x, v[7].y, v[8].x};
+        o.rot = Quat{v[8].y, v[9].x, v[9].y, v[10].x};
+        o.past_pos = Vec3{v[10].y, v[11].x, v[11].y};
+        return o;
+    }
+    return load_record(rec, i);
+}
+
+// Every thread of the workgroup calls this (it ends in a barrier): thread t stages the record of body `first + t`.
+__device__ __forceinline__ RecordStage stage_records(double2 *__restrict__ words, const double *__restrict__ rec, uint32_t first, uint32_t n)
+{
+    const uint32_t t = threadIdx.x, i = first + t;
+    if (i < n) {
+        const double2 *r = reinterpret_cast<const double2 *>(rec + (size_t)i * kRecDoubles);
+        double2 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            v[k] = r[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            words[k * kBlock + t] = v[k];
+    }
+    __syncthreads();
+    RecordStage s;
+    s.words = words;
+    s.first = first;
+    s.count = n > first ? (n - first < kBlock ? n - first : kBlock) : 0u;
+    return s;
+}
+
+// (past_pos: optional, the position before integrate -- only a body's own derive needs it)
+__device__ __forceinline__ PairBody load_pair_body(const ContactBuffers &c, uint32_t i, Vec3 *past_pos = nullptr,
+                                                   const RecordStage &stage = RecordStage())
+{
+    const BodyRecord r = load_record_staged(c.rec, i, stage); // two cache lines, or LDS
     const StatRecord s = load_stat_record(c.stat_rec, c.stat_index ? c.stat_index[i] : i); // one, or a cached table entry
     PairBody p;
     p.pos = r.pos;
@@ -673,7 +729,7 @@ __device__ __forceinline__ double generalized_inverse_mass(const PairBody &p, Ve
 template <uint32_t G>
 __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffers &c, uint32_t i, double h,
                                                               const PairBody &self, Vec3 self_past_pos, uint32_t sub, uint32_t &touching,
-                                                              uint32_t &points)
+                                                              uint32_t &points, const RecordStage &stage = RecordStage())
 {
     static_assert(G == 1 || G == kMaxManifoldPoints, "one lane per body or one lane per manifold point");
     const double compliance = 1e-6 / (h * h);
@@ -688,7 +744,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
             ++touching;
             points += n_points;
         }
-        const PairBody other = load_pair_body(c, j);
+        const PairBody other = load_pair_body(c, j, nullptr, stage);
         // pair (A, B) = (min, max); the reference body is A unless the reference face is on B.  The formulas are
         // written in terms of the incident and the reference body; here every term is evaluated for `self` and
         // `other` with their own point and only 3-vectors are selected by role -- selecting whole bodies by a
@@ -830,7 +886,7 @@ __device__ __forceinline__ BodyDynamic pair_solve_derive_body(const ContactBuffe
         for (uint32_t k = c.joint_off[i]; k < c.joint_off[i + 1]; ++k) {
             const Joint &jt = c.joints[c.joint_list[k]];
             const bool self_is_a = jt.body_a == i;
-            const PairBody other = load_pair_body(c, self_is_a ? jt.body_b : jt.body_a);
+            const PairBody other = load_pair_body(c, self_is_a ? jt.body_b : jt.body_a, nullptr, stage);
             // as above: evaluate per body, select 3-vectors by role (a / b)
             const Vec3 anchor_self = self_is_a ? Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]} : Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]};
             const Vec3 anchor_other = self_is_a ? Vec3{jt.anchor_b[0], jt.anchor_b[1], jt.anchor_b[2]} : Vec3{jt.anchor_a[0], jt.anchor_a[1], jt.anchor_a[2]};
@@ -916,11 +972,17 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
                                                                                         ContactBuffers c, BodySubset subset)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, slot = gid / G, sub = gid % G;
+    // one lane per body, bodies in index order: the workgroup's own records go through LDS (load_record_staged)
+    constexpr bool kStage = G == 1 && XPBD_PAIR_SOLVE_STAGE_RECORDS;
+    __shared__ double2 stage_words[kStage ? 12 * kBlock : 1];
+    RecordStage stage;
+    if (kStage && !subset.list)
+        stage = stage_records(stage_words, c.rec, blockIdx.x * kBlock, b.n);
     uint32_t touching = 0, points = 0, i;
     if (subset_body(subset, b.n, slot, i)) {
         Vec3 past_pos;
-        const PairBody self = load_pair_body(c, i, &past_pos);
-        const BodyDynamic d = pair_solve_derive_body<G>(c, i, h, self, past_pos, sub, touching, points);
+        const PairBody self = load_pair_body(c, i, &past_pos, stage);
+        const BodyDynamic d = pair_solve_derive_body<G>(c, i, h, self, past_pos, sub, touching, points, stage);
         if (sub == 0) {
             store_dynamic(dyn_out, b.stride, i, d);
             if (subset.export_rows)
@@ -952,6 +1014,11 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
     __syncthreads();
 
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, slot = gid / G, sub = gid % G;
+    constexpr bool kStage = G == 1 && XPBD_PAIR_SOLVE_STAGE_RECORDS; // see k_pair_solve_derive
+    __shared__ double2 stage_words[kStage ? 12 * kBlock : 1];
+    RecordStage stage;
+    if (kStage && !subset.list)
+        stage = stage_records(stage_words, c.rec, blockIdx.x * kBlock, b.n);
     uint32_t touching = 0, points = 0, i;
     if (subset_body(subset, b.n, slot, i)) {
         const uint32_t st = b.stride;
@@ -959,8 +1026,8 @@ __global__ void __launch_bounds__(kBlock, XPBD_PAIR_SOLVE_MIN_WAVES) k_pair_solv
         BodyStatic s;
         {
             Vec3 past_pos;
-            const PairBody self = load_pair_body(c, i, &past_pos);
-            d = pair_solve_derive_body<G>(c, i, h, self, past_pos, sub, touching, points);
+            const PairBody self = load_pair_body(c, i, &past_pos, stage);
+            d = pair_solve_derive_body<G>(c, i, h, self, past_pos, sub, touching, points, stage);
             s = static_of(b, i, self.inv_mass, self.inv_inertia, self.com);
         }
         if (subset.export_rows && sub == 0)

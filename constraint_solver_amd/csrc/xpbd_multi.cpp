@@ -28,7 +28,11 @@
 // on the device), and either re-run after a re-plan (XPBD_MULTI_AUTO_REPLAN) or reported as XPBD_E_HALO with the state of
 // the frame's start in place.  A state with possibly missed contacts never reaches the caller.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -381,6 +385,50 @@ struct Shard {
     double *status_host = nullptr; // pinned, this process's status of the frame
 };
 
+// One host thread per local shard (a process that owns several GPUs): a frame is ~20 runtime calls per shard and substep, and
+// a single thread enqueueing them for 8 GPUs takes longer than the GPUs need to run them (measured on one device with four
+// shards: 5.5 ms of enqueueing per 4.4 ms frame, profiles/r03_a_multi_host_time.json).  The threads meet at a barrier only
+// where the in-process transport needs every shard's event to have been RECORDED before anybody waits for it.
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t n = 1, waiting = 0;
+    uint64_t generation = 0;
+    void arrive_and_wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        const uint64_t g = generation;
+        if (++waiting == n) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return generation != g; });
+        }
+    }
+};
+
+struct ShardJob {
+    int rc = XPBD_OK;           // first local error of the shard's frame (LocalStatus)
+    std::string message;
+    int fatal = XPBD_OK;        // a collective could not be enqueued
+    std::string fatal_message;
+    uint64_t ns_wait_broadphase = 0;
+};
+
+struct Workers {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    uint64_t job = 0;
+    uint32_t done = 0;
+    bool quit = false;
+    double dt = 0.0;
+    uint32_t substeps = 0;
+    std::vector<ShardJob> result;
+    Barrier barrier;
+};
+
 } // namespace
 
 struct xpbd_multi_world {
@@ -397,6 +445,7 @@ struct xpbd_multi_world {
     uint64_t plans = 0, rollbacks = 0, migrated = 0, steps = 0, ns_enqueue = 0, ns_wait_broadphase = 0, ns_wait_frame = 0;
     double cell_edge = 0.0;
     double last_displacement = 0.0; // the largest fraction of its travel allowance any body had used at the last check, times halo_margin
+    Workers *workers = nullptr;     // one enqueueing thread per local shard (n_local > 1), started by the first step
     bool all_local() const { return shards.size() == n_ranks; }
     bool shortcut() const { return all_local() && !(flags & XPBD_MULTI_PLAN_THROUGH_DEVICE); } // plan-time gathers are memcpys
     uint32_t rows_per_rank() const { return capacity; }
@@ -1037,6 +1086,182 @@ int enqueue_frame(xpbd_multi_world *mw, double dt, uint32_t substeps, LocalStatu
     return XPBD_OK;
 }
 
+// ---- the same frame with one enqueueing thread per local shard -----------------------------------------------------------------
+// What thread k does for shard k is what enqueue_frame does for it, in the same order on the same streams; the collectives:
+//   RCCL   each thread calls ncclAllGather on its own communicator (one thread per device, no group call);
+//   local  record my send event | BARRIER | wait for the peers' send events, copy their rows, record my receive event |
+//          BARRIER | wait for the peers' receive events (nobody overwrites a send buffer that is still being read).
+// Every thread passes every barrier whatever went wrong (errors only skip the runtime calls), so nobody is left waiting.
+void shard_frame(xpbd_multi_world *mw, size_t k, double dt, uint32_t substeps, ShardJob &job, Barrier &bar)
+{
+    Shard &s = mw->shards[k];
+    const bool multi = mw->n_ranks > 1;
+    const double h = dt / (double)substeps; // src/solver.rs:4
+    LocalStatus st;
+    auto hip_keep = [&st](hipError_t e, const char *what) {
+        if (e != hipSuccess)
+            st.keep(set_error(XPBD_E_HIP, "%s failed: %s", what, hipGetErrorString(e)));
+    };
+    auto fatal = [&job](int rc) {
+        if (job.fatal == XPBD_OK && rc != XPBD_OK) {
+            job.fatal = rc;
+            job.fatal_message = xpbd_last_error();
+        }
+    };
+    auto fatal_hip = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess)
+            fatal(set_error(XPBD_E_HIP, "%s failed: %s", what, hipGetErrorString(e)));
+    };
+    // one all-gather: `bytes` from send_of(me) into my recv at row rank, for every rank
+    auto gather = [&](size_t bytes, void *(*send_of)(Shard &), void *recv, hipStream_t stream, hipStream_t (*stream_of)(Shard &)) {
+        (void)stream_of;
+        if (mw->transport == XPBD_TRANSPORT_RCCL) {
+            if (job.fatal == XPBD_OK) {
+                (void)hipGetLastError(); // see all_gather_device_raw
+                const ncclResult_t r = mw->rccl->AllGather(send_of(s), recv, bytes, ncclChar, s.comm, stream);
+                if (r != ncclSuccess)
+                    fatal(nccl_fail(mw, r, "ncclAllGather"));
+            }
+            return;
+        }
+        if (job.fatal == XPBD_OK)
+            fatal_hip(hipEventRecord(s.ev_send, stream), "hipEventRecord");
+        bar.arrive_and_wait(); // every shard's send event has been recorded
+        if (job.fatal == XPBD_OK) {
+            for (Shard &p : mw->shards) {
+                if (&p != &s)
+                    fatal_hip(hipStreamWaitEvent(stream, p.ev_send, 0), "hipStreamWaitEvent");
+                fatal_hip(hipMemcpyAsync(static_cast<char *>(recv) + (size_t)p.rank * bytes, send_of(p), bytes, hipMemcpyDefault, stream), "hipMemcpyAsync");
+            }
+            fatal_hip(hipEventRecord(s.ev_recv, stream), "hipEventRecord");
+        }
+        bar.arrive_and_wait(); // every shard's receive event has been recorded
+        if (job.fatal == XPBD_OK)
+            for (Shard &r : mw->shards)
+                if (&r != &s)
+                    fatal_hip(hipStreamWaitEvent(stream, r.ev_recv, 0), "hipStreamWaitEvent");
+    };
+    st.keep(bind(s));
+    if (multi && st.ok())
+        st.keep(xpbd::frame_snapshot_save(s.world));
+    if (st.ok())
+        st.keep(xpbd::halo_frame_begin_enqueue(s.world, dt));
+    const uint64_t t0 = now_ns();
+    if (st.ok())
+        st.keep(xpbd::halo_frame_begin_collect(s.world, h));
+    job.ns_wait_broadphase = now_ns() - t0;
+    const xpbd::HaloLists lists{s.boundary_slots.as<uint32_t>(), (uint32_t)s.boundary.size(), s.ghost_slots.as<uint32_t>(), s.ghost_rows.as<uint32_t>(),
+                                (uint32_t)s.ghosts.size(), s.skip_flags.as<uint8_t>(), s.send.as<double>(), s.recv.as<double>()};
+    const size_t bytes = (size_t)mw->rows_per_rank() * kDyn * 8;
+    for (uint32_t q = 0; q < substeps; ++q) {
+        const bool last = q + 1 == substeps;
+        if (st.ok())
+            st.keep(xpbd::halo_substep_boundary(s.world, h, q, last, lists));
+        if (multi) {
+            hip_keep(hipEventRecord(s.ev_ready, s.stream), "hipEventRecord");
+            hip_keep(hipStreamWaitEvent(s.comm_stream, s.ev_ready, 0), "hipStreamWaitEvent");
+            gather(bytes, [](Shard &x) -> void * { return x.send.ptr; }, s.recv.ptr, s.comm_stream, nullptr);
+            hip_keep(hipEventRecord(s.ev_gathered, s.comm_stream), "hipEventRecord");
+        }
+        if (st.ok())
+            st.keep(xpbd::halo_substep_interior(s.world, h, q, last, lists));
+        if (multi) {
+            hip_keep(hipStreamWaitEvent(s.stream, s.ev_gathered, 0), "hipStreamWaitEvent");
+            if (st.ok())
+                st.keep(xpbd::halo_substep_ghosts(s.world, h, q, last, lists));
+        }
+    }
+    if (multi) {
+        hip_keep(hipMemsetAsync(s.disp.ptr, 0, 16, s.stream), "hipMemsetAsync");
+        if (st.ok())
+            st.keep(xpbd_world_max_displacement2(s.world, s.owned_slots.as<uint32_t>(), (uint32_t)s.held_ids.size(), s.snapshot.as<double>(),
+                                                 s.disp_scale.as<double>(), s.disp.as<double>()));
+        *s.status_host = (double)st.rc;
+        hip_keep(hipMemcpyAsync(s.disp.as<double>() + 1, s.status_host, 8, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+        gather(16, [](Shard &x) -> void * { return x.disp.ptr; }, s.disp_all.ptr, s.stream, nullptr);
+        hip_keep(hipMemcpyAsync(s.disp_host, s.disp_all.ptr, (size_t)mw->n_ranks * 16, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+    }
+    job.rc = st.rc;
+    job.message = st.message;
+}
+
+void worker_main(xpbd_multi_world *mw, size_t k)
+{
+    Workers &w = *mw->workers;
+    uint64_t seen = 0;
+    for (;;) {
+        double dt;
+        uint32_t substeps;
+        {
+            std::unique_lock<std::mutex> lock(w.m);
+            w.cv_job.wait(lock, [&] { return w.quit || w.job != seen; });
+            if (w.quit)
+                return;
+            seen = w.job;
+            dt = w.dt, substeps = w.substeps;
+        }
+        w.result[k] = ShardJob();
+        shard_frame(mw, k, dt, substeps, w.result[k], w.barrier);
+        {
+            std::lock_guard<std::mutex> lock(w.m);
+            ++w.done;
+        }
+        w.cv_done.notify_one();
+    }
+}
+
+int enqueue_frame_threaded(xpbd_multi_world *mw, double dt, uint32_t substeps, LocalStatus &st)
+{
+    const uint64_t t0 = now_ns();
+    if (!mw->workers) {
+        mw->workers = new (std::nothrow) Workers;
+        if (!mw->workers)
+            return set_error(XPBD_E_OOM, "xpbd_multi_world_step: host allocation failed");
+        Workers &w = *mw->workers;
+        w.result.resize(mw->shards.size());
+        w.barrier.n = (uint32_t)mw->shards.size();
+        for (size_t k = 0; k < mw->shards.size(); ++k)
+            w.threads.emplace_back(worker_main, mw, k);
+    }
+    Workers &w = *mw->workers;
+    {
+        std::unique_lock<std::mutex> lock(w.m);
+        w.dt = dt, w.substeps = substeps, w.done = 0;
+        ++w.job;
+        w.cv_job.notify_all();
+        w.cv_done.wait(lock, [&] { return w.done == (uint32_t)w.threads.size(); });
+    }
+    uint64_t wait = 0;
+    for (const ShardJob &j : w.result)
+        wait = std::max(wait, j.ns_wait_broadphase);
+    mw->ns_wait_broadphase += wait;
+    mw->ns_enqueue += (now_ns() - t0) - wait;
+    for (const ShardJob &j : w.result)
+        if (j.fatal != XPBD_OK)
+            return transport_broken(mw, set_error(j.fatal, "%s", j.fatal_message.c_str()));
+    for (const ShardJob &j : w.result)
+        if (j.rc != XPBD_OK && st.ok()) {
+            st.rc = j.rc;
+            st.message = j.message;
+        }
+    return XPBD_OK;
+}
+
+void stop_workers(xpbd_multi_world *mw)
+{
+    if (!mw->workers)
+        return;
+    {
+        std::lock_guard<std::mutex> lock(mw->workers->m);
+        mw->workers->quit = true;
+    }
+    mw->workers->cv_job.notify_all();
+    for (std::thread &t : mw->workers->threads)
+        t.join();
+    delete mw->workers;
+    mw->workers = nullptr;
+}
+
 // Waits for the frame's last exchange.  *moved = the largest fraction of its travel allowance any owned body of any rank
 // has used since the plan, in margin-equivalent metres (x halo_margin): a body next to a shard boundary may travel
 // halo_margin, one more than two cells away from every foreign body halo_margin + half a cell edge (HaloPlanner::plan_rank).
@@ -1085,6 +1310,7 @@ void destroy(xpbd_multi_world *mw)
 {
     if (!mw)
         return;
+    stop_workers(mw);
     for (Shard &s : mw->shards) {
         (void)hipSetDevice(s.device);
         if (s.stream)
@@ -1183,7 +1409,7 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: XPBD_TRANSPORT_RCCL needs comm_id (xpbd_comm_unique_id on one rank, handed to all)");
     if (!(cfg->contact_pad >= 0.0) || !(cfg->halo_margin > 0.0) || cfg->contact_pad > 1.0e6 || cfg->halo_margin > 1.0e6)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: contact_pad %g / halo_margin %g", cfg->contact_pad, cfg->halo_margin);
-    if (cfg->flags & ~(XPBD_MULTI_AUTO_REPLAN | XPBD_MULTI_PLAN_THROUGH_DEVICE))
+    if (cfg->flags & ~(XPBD_MULTI_AUTO_REPLAN | XPBD_MULTI_PLAN_THROUGH_DEVICE | XPBD_MULTI_SERIAL_ENQUEUE))
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: unknown flags 0x%x", cfg->flags);
     if (cfg->narrowphase != XPBD_NARROWPHASE_SAT && cfg->narrowphase != XPBD_NARROWPHASE_GJK_EPA)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: unknown narrowphase %u", cfg->narrowphase);
@@ -1364,7 +1590,10 @@ int xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps)
     ++mw->steps;
     for (int attempt = 0;; ++attempt) {
         LocalStatus st;
-        MW_TRY(enqueue_frame(mw, dt, substeps, st));
+        if (mw->shards.size() > 1 && !(mw->flags & XPBD_MULTI_SERIAL_ENQUEUE))
+            MW_TRY(enqueue_frame_threaded(mw, dt, substeps, st));
+        else
+            MW_TRY(enqueue_frame(mw, dt, substeps, st));
         if (mw->n_ranks == 1)
             return st.ok() ? XPBD_OK : st.report(); // no ghosts, nothing to validate: asynchronous after the broadphase
         double moved = 0.0;

@@ -348,7 +348,10 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
  * pass consistent arguments.  A rank that never reaches xpbd_multi_world_create leaves its peers waiting inside RCCL's
  * bootstrap; only the host's launcher can detect that.
  * Threading: xpbd_multi_world_step waits once for the broadphase's pair counts (all shards' broadphases are enqueued before
- * the first wait) and, with n_ranks > 1, for the end of the frame (the validity check).
+ * the first wait) and, with n_ranks > 1, for the end of the frame (the validity check).  A world with several LOCAL shards
+ * enqueues their frames from one host thread per shard (started by the first step, joined by destroy): a frame is ~20 runtime
+ * calls per shard and substep, more than one thread can issue for 8 GPUs in the time the GPUs need to run them.  The caller
+ * still uses the world from one thread at a time.
  * The RCCL transport has run on hardware with a ONE-rank communicator only (the build box has one GPU and RCCL refuses two
  * ranks on one device); everything else is verified with XPBD_TRANSPORT_LOCAL.
  * ------------------------------------------------------------------------- */
@@ -356,6 +359,8 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
 #define XPBD_TRANSPORT_RCCL  0u
 #define XPBD_TRANSPORT_LOCAL 1u         /* needs n_local == n_ranks */
 #define XPBD_MULTI_AUTO_REPLAN 1u
+#define XPBD_MULTI_SERIAL_ENQUEUE 4u      /* diagnostics: one host thread enqueues all local shards' frames (default with several
+                                           * local shards: one enqueueing thread per shard, see Threading above) */
 #define XPBD_MULTI_PLAN_THROUGH_DEVICE 2u /* diagnostics: the plan-time all-gathers go through the device transport even when
                                            * every rank lives in this process (the path a one-process-per-GPU run takes) */
 

@@ -23,10 +23,12 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--substeps", type=int, default=20)
+    ap.add_argument("--serial-enqueue", action="store_true", help="XPBD_MULTI_SERIAL_ENQUEUE: one host thread enqueues all shards")
     args = ap.parse_args()
     kind = capi.SCENE_BOX_STACKS
     bodies, sid = capi.scene_generate(kind, 1, args.bodies, grid_w=capi.default_grid_width(max(args.bodies // 16 // args.shards, 1)))
-    with capi.MultiWorld(args.shards, devices=[0] * args.shards, transport=capi.TRANSPORT_LOCAL, halo_margin=0.5, auto_replan=True) as mw:
+    extra = {"serial_enqueue": True} if args.serial_enqueue else {}
+    with capi.MultiWorld(args.shards, devices=[0] * args.shards, transport=capi.TRANSPORT_LOCAL, halo_margin=0.5, auto_replan=True, **extra) as mw:
         mw.set_polytopes(capi.scene_polytopes(kind))
         t0 = time.perf_counter()
         mw.upload(bodies, sid, 0, args.bodies)
@@ -47,6 +49,7 @@ def main():
         mw.synchronize()
         wall = time.perf_counter() - t_all
         out = {"library": os.environ.get("XPBD_HIP_LIB", "constraint_solver_amd/lib/libxpbd_hip.so"), "shards": args.shards,
+               "enqueue": "one host thread" if args.serial_enqueue else "one host thread per shard",
                "bodies": args.bodies, "frames": args.frames, "substeps": args.substeps, "upload_and_plan_ms": upload_ms,
                "wall_ms_per_frame": wall * 1e3 / args.frames, "step_call_ms_per_frame": in_call * 1e3 / args.frames,
                "halo": mw.halo_stats(), "body_substeps_per_s": args.bodies * args.substeps * args.frames / wall}
