@@ -33,9 +33,13 @@ constexpr uint32_t kHitSegments = 32;
 constexpr uint32_t kHitCounterStride = 32; // uint32: 128 bytes
 constexpr size_t gjk_counter_bytes() { return (size_t)2 * kHitSegments * kHitCounterStride * 4; }
 // `axis_cache` (3 doubles per pair, or null; needs the pre-test as a pass of its own): the direction whose support plane
-// proved a pair separated in its last query, zero = none.  The pre-test pass tries it before the pair is sent to GJK again
-// (semantics: og_gjk_epa_cached of the oracle -- in a settled pile most separated pairs stay separated by the same plane
-// from one substep to the next); every full query refreshes it, the owner zeroes it with every new pair list.
+// proved a pair separated in its last query, or its last PENETRATION NORMAL; zero = none.  The pre-test pass tries it as a
+// separating plane before the pair is sent to GJK again (in a settled pile most separated pairs stay separated by the same
+// plane from one substep to the next), and the full query WARM-STARTS its expansion with it: the polytope is seeded with
+// the face of the Minkowski difference that has that normal, which makes the boolean GJK unnecessary and lets the
+// expansion of two bodies resting face on face end in its first iteration instead of the seventh (semantics:
+// og_gjk_epa_cached / seed_polytope of the oracle).  Every full query refreshes it, the owner zeroes it with every new
+// pair list.
 struct GjkScratch {
     uint32_t *counters;
     void *pairs_scratch;

@@ -41,6 +41,12 @@ struct GjkVertsT {
 };
 using GjkVerts = GjkVertsT<kMaxV>;
 
+// ... and, in k_gjk_pairs, the (at most five) vertices of a warm-start polytope, where make_face reads them
+template <uint32_t V>
+struct GjkPairLds : GjkVertsT<V> {
+    double vw[5][3];
+};
+
 struct GjkLds : GjkVerts {
     double vw[kMaxEpaVerts][3];                                                // polytope vertices w = wa[via] - wb[vib]
     uint8_t via[kMaxEpaVerts], vib[kMaxEpaVerts];                              // their witnesses, as vertex indices
@@ -276,12 +282,93 @@ __device__ __forceinline__ PolytopeTables stage_tables(const PolytopeTables &t, 
     return l;
 }
 
-// Vertex indices of the four simplex points: byte k = A's index of point k, byte 4 + k = B's.
+// What k_gjk_pairs hands to the EPA kernels, two words per pair.  Word 0: vertex indices of the first four polytope points
+// (byte k = A's index of point k, byte 4 + k = B's).  Word 1: byte 0 / 1 = A's / B's index of a fifth point, byte 2 = the
+// MODE: 0 = the four points are GJK's final tetrahedron; m = 3 or 4 = a WARM-START pyramid (below): points 0 .. m - 1 are its
+// top, point m its apex.
 __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const MVert &s1, const MVert &s2, const MVert &s3)
 {
     const unsigned long long a = s0.ia | (s1.ia << 8) | (s2.ia << 16) | (s3.ia << 24);
     const unsigned long long b = s0.ib | (s1.ib << 8) | (s2.ib << 16) | (s3.ib << 24);
     return a | (b << 32);
+}
+
+// WARM START of the expansion (oracle: seed_polytope of xpbd_gjk_oracle.c, which is the normative text).  `warm` is the pair's
+// cached direction: its last penetration normal, or the direction that separated it before it came into contact.  The polytope
+// is seeded with the face of the Minkowski difference that has (nearly) that normal: four support points in directions tilted
+// by kWarmTilt towards the diagonals of a tangent frame, duplicates dropped, plus the support point of -n as the apex.  Face f
+// of the pyramid over m = 3 or 4 top points: the top fan (0, f + 1, f + 2) for f < m - 2 (opposite vertex: the apex m), then the
+// sides ((k + 1) % m, k, m), k = f - (m - 2) (opposite vertex: (k + 2) % m).
+constexpr double kWarmTilt = 1e-3, kWarmConvex = 1e-10;
+// (i0 | i1 << 8 | i2 << 16 | opposite << 24)
+__device__ __forceinline__ uint32_t warm_face_indices(uint32_t f, uint32_t m)
+{
+    if (f + 2 < m)
+        return 0u | ((f + 1) << 8) | ((f + 2) << 16) | (m << 24);
+    const uint32_t k = f - (m - 2);
+    const uint32_t k1 = k + 1 == m ? 0u : k + 1, k2 = k1 + 1 == m ? 0u : k1 + 1; // (k + 1) % m, (k + 2) % m
+    return k1 | (k << 8) | (m << 16) | (k2 << 24);
+}
+
+// By a group of L lanes (all lanes return the same verdict and, when it is true, the same points v[0 .. m] and m): is the
+// pyramid sound, convex and around the origin?  Then the pair is penetrating and GJK is not needed.
+template <uint32_t L, class Lds>
+__device__ __forceinline__ bool warm_seed(Lds &s, uint32_t na, uint32_t nb, Vec3 warm, uint32_t lane, MVert &v0, MVert &v1, MVert &v2,
+                                          MVert &v3, MVert &v4, uint32_t &m_out)
+{
+    const double len = length(warm);
+    if (!(len > 0.0) || !(len <= DBL_MAX)) // group-uniform
+        return false;
+    const Vec3 n = warm * (1.0 / len);
+    const double ax = fabs(n.x), ay = fabs(n.y), az = fabs(n.z);
+    const bool use_x = ax <= ay && ax <= az, use_y = !use_x && ay <= az;
+    const Vec3 e{use_x ? 1.0 : 0.0, use_y ? 1.0 : 0.0, (use_x || use_y) ? 0.0 : 1.0};
+    const Vec3 t1 = normalized(cross(n, e)), t2 = cross(n, t1);
+    // the four tilted support points, in the order (+t1 +t2), (-t1 +t2), (-t1 -t2), (+t1 -t2)
+    const MVert q0 = minkowski_support<L>(s, na, nb, n + ((1.0 * kWarmTilt) * t1 + (1.0 * kWarmTilt) * t2), lane);
+    const MVert q1 = minkowski_support<L>(s, na, nb, n + ((-1.0 * kWarmTilt) * t1 + (1.0 * kWarmTilt) * t2), lane);
+    const MVert q2 = minkowski_support<L>(s, na, nb, n + ((-1.0 * kWarmTilt) * t1 + (-1.0 * kWarmTilt) * t2), lane);
+    const MVert q3 = minkowski_support<L>(s, na, nb, n + ((1.0 * kWarmTilt) * t1 + (-1.0 * kWarmTilt) * t2), lane);
+    auto same = [](const MVert &x, const MVert &y) { return x.ia == y.ia && x.ib == y.ib; };
+    // duplicates dropped (a point equal to an earlier one; everything below is group-uniform: every lane holds the same points)
+    const bool k1 = !same(q1, q0), k2 = !same(q2, q0) && !same(q2, q1), k3 = !same(q3, q0) && !same(q3, q1) && !same(q3, q2);
+    const uint32_t m = 1u + (k1 ? 1u : 0u) + (k2 ? 1u : 0u) + (k3 ? 1u : 0u);
+    if (m < 3)
+        return false;
+    v0 = q0;
+    v1 = k1 ? q1 : q2;                  // (m >= 3: at most one of the three was dropped)
+    v2 = (k1 && k2) ? q2 : q3;
+    const MVert apex = minkowski_support<L>(s, na, nb, -n, lane);
+    if (same(apex, v0) || same(apex, v1) || same(apex, v2) || (m == 4 && same(apex, q3)))
+        return false;
+    v3 = m == 4 ? q3 : apex;
+    v4 = apex;
+    // the faces, one per lane, from the points in LDS
+    __syncthreads();
+    if (lane == 0) {
+        st3(s.vw, 0, v0.w);
+        st3(s.vw, 1, v1.w);
+        st3(s.vw, 2, v2.w);
+        st3(s.vw, 3, v3.w);
+        st3(s.vw, 4, v4.w);
+    }
+    __syncthreads();
+    const uint32_t nf = (m - 2) + m;
+    bool ok = true;
+    if (lane < nf) {
+        const uint32_t idx = warm_face_indices(lane, m);
+        const Face f = make_face(s, idx & 0xFFu, (idx >> 8) & 0xFFu, (idx >> 16) & 0xFFu, idx >> 24);
+        ok = f.ok && f.dist >= 0.0; // sound, and the origin inside or on it
+        const Vec3 p0 = ld3(s.vw, f.i0);
+        for (uint32_t q = 0; q <= m; ++q)
+            ok = ok && dot(f.n, ld3(s.vw, q) - p0) <= kWarmConvex; // convex with exactly this face structure
+    }
+    static_assert(L >= 8, "six faces, one per lane");
+    const unsigned long long wave_bad = __ballot(!ok);
+    const uint32_t first = (threadIdx.x & 63u) / L * L;
+    const unsigned long long group_bad = L == 64 ? wave_bad : (wave_bad >> first) & ((1ull << (L & 63u)) - 1ull);
+    m_out = m;
+    return group_bad == 0;
 }
 
 // Boolean GJK, L lanes per pair.  out / manifolds (each optional) receive the verdict of every pair that is NOT
@@ -305,10 +392,10 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     unsigned long long tick_ = clock64();
 #endif
     constexpr uint32_t PW = 64 / L; // pairs per wave
-    __shared__ GjkVertsT<V> s_all[PW];
+    __shared__ GjkPairLds<V> s_all[PW];
     __shared__ StagedTables staged;
     const PolytopeTables t = stage_tables<STAGED>(t_global, staged);
-    GjkVertsT<V> &s = s_all[threadIdx.x / L];
+    GjkPairLds<V> &s = s_all[threadIdx.x / L];
     const uint32_t slot = blockIdx.x * PW + threadIdx.x / L;
     const uint32_t lane = threadIdx.x % L; // lane inside this pair's group
     if (survivors) {
@@ -348,7 +435,24 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     uint32_t gjk_iters = 0;
     MVert s0{}, s1{}, s2{}, s3{};
     Vec3 separating{0.0, 0.0, 0.0}; // the direction whose support plane proves the pair separated (GjkScratch::axis_cache)
-    if (usable) {
+    // warm start: the pair's cached direction seeds the polytope and, if the seed holds, replaces the boolean GJK
+    unsigned long long seed_word1 = 0;
+    bool seeded = false;
+    if (usable && axis_cache) {
+        const double *c = axis_cache + 3 * (size_t)p;
+        const Vec3 warm{c[0], c[1], c[2]};
+        if (dot(warm, warm) > 0.0) { // group-uniform
+            MVert v0{}, v1{}, v2{}, v3{}, v4{};
+            uint32_t m = 0;
+            if (warm_seed<L>(s, da.n_verts, db.n_verts, warm, lane, v0, v1, v2, v3, v4, m)) {
+                seeded = true;
+                status = 1;
+                s0 = v0, s1 = v1, s2 = v2, s3 = v3;
+                seed_word1 = (m == 4 ? (unsigned long long)(v4.ia | (v4.ib << 8)) : 0ull) | ((unsigned long long)m << 16);
+            }
+        }
+    }
+    if (usable && !seeded) {
         const uint32_t na = da.n_verts, nb = db.n_verts;
         uint32_t n = 1;
         Vec3 d;
@@ -439,7 +543,8 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
         if (hit) {
             const uint32_t slot = base + (uint32_t)__popcll(hit_mask & ((1ull << threadIdx.x) - 1ull));
             hits[(size_t)segment * segment_capacity + slot] = p;
-            seeds[p] = pack_seed(s0, s1, s2, s3);
+            seeds[2 * (size_t)p] = pack_seed(s0, s1, s2, s3);
+            seeds[2 * (size_t)p + 1] = seed_word1;
         }
     }
     GJK_TICK(3); // verdicts and hit list
@@ -459,13 +564,16 @@ constexpr double kFaceAlign = 0.999; // cosine: 2.6 degrees
 template <uint32_t L, class S>
 __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const ShapeDesc &da, const ShapeDesc &db, const Frame &fa,
                                          const Frame &fb, uint32_t best, double best_dist, GjkResult *__restrict__ r,
-                                         ContactManifold *__restrict__ mf, uint8_t *__restrict__ code, uint32_t lane)
+                                         ContactManifold *__restrict__ mf, uint8_t *__restrict__ code, double *__restrict__ axis, uint32_t lane)
 {
     constexpr uint32_t P = L < 16 ? L : 16;
     static_assert(sizeof(s.vw) >= P * 3 * sizeof(double) && sizeof(s.fn) >= (P + kMaxFaceVerts) * 3 * sizeof(double),
                   "the clipper reuses the polytope's vertex rows and face normals");
     const Vec3 nrm = ld3(s.fn, best);
     Vec3 pa{0.0, 0.0, 0.0}, pb{0.0, 0.0, 0.0};
+    if (lane == 0 && axis) { // the penetration normal warm-starts the pair's next expansion (GjkScratch::axis_cache)
+        axis[0] = nrm.x, axis[1] = nrm.y, axis[2] = nrm.z;
+    }
     if (lane == 0) {
         const uint32_t i0 = face_vertex(s.fi[best], 0), i1 = face_vertex(s.fi[best], 1), i2 = face_vertex(s.fi[best], 2);
         const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
@@ -525,9 +633,9 @@ __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const Sh
 
 // EPA of one penetrating pair by one wave; the polytope starts from the simplex k_gjk_pairs left.
 __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
-                                         const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
+                                         const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed, unsigned long long seed1,
                                          GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint8_t *__restrict__ codes,
-                                         uint32_t lane)
+                                         double *__restrict__ axis_cache, uint32_t lane)
 {
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
@@ -550,21 +658,31 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 
     stage_world_vertices(s, t, da, db, fa, fb, lane, 64);
     __syncthreads();
-    if (lane < 4) {
-        const uint32_t va = (uint32_t)(seed >> (8 * lane)) & 0xFFu, vb = (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu;
+    // the first polytope: GJK's tetrahedron, or the warm-start pyramid over m top points (pack_seed)
+    const uint32_t warm_m = (uint32_t)(seed1 >> 16) & 0xFFu;
+    uint32_t nv = warm_m ? warm_m + 1u : 4u, nf = warm_m ? 2u * warm_m - 2u : 4u;
+    if (lane < nv) {
+        const uint32_t va = lane < 4 ? (uint32_t)(seed >> (8 * lane)) & 0xFFu : (uint32_t)seed1 & 0xFFu;
+        const uint32_t vb = lane < 4 ? (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu : (uint32_t)(seed1 >> 8) & 0xFFu;
         const Vec3 a = ld3(s.wa, va), bb = ld3(s.wb, vb);
         st3(s.vw, lane, a - bb);
         s.via[lane] = (uint8_t)va, s.vib[lane] = (uint8_t)vb;
     }
     __syncthreads();
-    uint32_t nv = 4, nf = 4;
     {
         bool bad = false;
-        if (lane < 4) {
-            const uint32_t t0 = lane == 3 ? 1u : 0u;
-            const uint32_t t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
-            const uint32_t t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
-            const Face f = make_face(s, t0, t1, t2, 3u - lane); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}: face k lacks vertex 3 - k
+        if (lane < nf) {
+            uint32_t t0, t1, t2, opposite;
+            if (warm_m) {
+                const uint32_t idx = warm_face_indices(lane, warm_m);
+                t0 = idx & 0xFFu, t1 = (idx >> 8) & 0xFFu, t2 = (idx >> 16) & 0xFFu, opposite = idx >> 24;
+            } else { // {0,1,2} {0,3,1} {0,2,3} {1,3,2}: face k lacks vertex 3 - k
+                t0 = lane == 3 ? 1u : 0u;
+                t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
+                t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
+                opposite = 3u - lane;
+            }
+            const Face f = make_face(s, t0, t1, t2, opposite);
             store_face(s, lane, f);
             bad = !f.ok;
         }
@@ -686,7 +804,7 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 
     double best_dist;
     const uint32_t best = closest_face(s, nf, lane, &best_dist);
-    epa_emit<64>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, lane);
+    epa_emit<64>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, axis_cache ? axis_cache + 3 * (size_t)p : nullptr, lane);
     finish(1);
 }
 
@@ -763,9 +881,9 @@ __device__ __forceinline__ unsigned long long group_ballot(bool flag)
 // returns false when the hit outgrew the small polytope (nothing has been written for it then)
 template <uint32_t L>
 __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
-                                             const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed,
+                                             const uint32_t *__restrict__ pairs, uint32_t p, unsigned long long seed, unsigned long long seed1,
                                              GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds, uint8_t *__restrict__ codes,
-                                             uint32_t lane)
+                                             double *__restrict__ axis_cache, uint32_t lane)
 {
     static_assert(kSubPolyFaces <= 64 && L * 4 >= kSubPolyFaces, "face flags live in one 64-bit mask; at most four faces per lane");
     static_assert(kSubRows <= 32, "the directed-edge marks are 32-bit rows");
@@ -811,21 +929,31 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 
     stage_world_vertices(s, t, da, db, fa, fb, lane, L);
     __syncthreads();
-    if (lane < 4) {
-        const uint32_t va = (uint32_t)(seed >> (8 * lane)) & 0xFFu, vb = (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu;
+    // the first polytope: GJK's tetrahedron, or the warm-start pyramid over m top points (pack_seed)
+    const uint32_t warm_m = (uint32_t)(seed1 >> 16) & 0xFFu;
+    uint32_t nv = warm_m ? warm_m + 1u : 4u, nf = warm_m ? 2u * warm_m - 2u : 4u;
+    if (lane < nv) {
+        const uint32_t va = lane < 4 ? (uint32_t)(seed >> (8 * lane)) & 0xFFu : (uint32_t)seed1 & 0xFFu;
+        const uint32_t vb = lane < 4 ? (uint32_t)(seed >> (32 + 8 * lane)) & 0xFFu : (uint32_t)(seed1 >> 8) & 0xFFu;
         const Vec3 a = ld3(s.wa, va), bb = ld3(s.wb, vb);
         st3(s.vw, lane, a - bb);
         s.via[lane] = (uint8_t)va, s.vib[lane] = (uint8_t)vb;
     }
     __syncthreads();
-    uint32_t nv = 4, nf = 4;
     {
         bool bad = false;
-        if (lane < 4) {
-            const uint32_t t0 = lane == 3 ? 1u : 0u;
-            const uint32_t t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
-            const uint32_t t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
-            const Face f = make_face(s, t0, t1, t2, 3u - lane); // {0,1,2} {0,3,1} {0,2,3} {1,3,2}: face k lacks vertex 3 - k
+        if (lane < nf) {
+            uint32_t t0, t1, t2, opposite;
+            if (warm_m) {
+                const uint32_t idx = warm_face_indices(lane, warm_m);
+                t0 = idx & 0xFFu, t1 = (idx >> 8) & 0xFFu, t2 = (idx >> 16) & 0xFFu, opposite = idx >> 24;
+            } else { // {0,1,2} {0,3,1} {0,2,3} {1,3,2}: face k lacks vertex 3 - k
+                t0 = lane == 3 ? 1u : 0u;
+                t1 = lane == 0 ? 1u : (lane == 1 ? 3u : (lane == 2 ? 2u : 3u));
+                t2 = lane == 0 ? 2u : (lane == 1 ? 1u : (lane == 2 ? 3u : 2u));
+                opposite = 3u - lane;
+            }
+            const Face f = make_face(s, t0, t1, t2, opposite);
             store_face(s, lane, f);
             bad = !f.ok;
         }
@@ -946,7 +1074,7 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
 
     double best_dist;
     const uint32_t best = closest(nf, &best_dist);
-    epa_emit<L>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, lane);
+    epa_emit<L>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, axis_cache ? axis_cache + 3 * (size_t)p : nullptr, lane);
     finish(1);
     return true;
 }
@@ -966,7 +1094,7 @@ k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frame
                                                       uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
                                                       uint32_t segment_capacity, const unsigned long long *__restrict__ seeds,
                                                       uint32_t *__restrict__ overflow_count, uint32_t *__restrict__ overflow,
-                                                      uint8_t *__restrict__ codes)
+                                                      uint8_t *__restrict__ codes, double *__restrict__ axis_cache)
 {
     constexpr uint32_t PW = 64 / L;
     __shared__ EpaSubLds s_all[PW];
@@ -978,7 +1106,7 @@ k_epa_pairs_sub(BodyArrays b, PolytopeTables t, const double *__restrict__ frame
     const uint32_t n_hits = hit_list_open(prefix, hit_counts, kHitSegments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x * PW + threadIdx.x / L; h < n_hits; h += gridDim.x * PW) {
         const uint32_t p = hit_list_entry(prefix, kHitSegments, hits, segment_capacity, h);
-        const bool done = epa_pair_sub<L>(s, b, t, frames, pairs, p, seeds[p], out, manifolds, codes, lane);
+        const bool done = epa_pair_sub<L>(s, b, t, frames, pairs, p, seeds[2 * (size_t)p], seeds[2 * (size_t)p + 1], out, manifolds, codes, axis_cache, lane);
         if (!done) {
             // the marks of the interrupted iteration were cleared before the exits; hand the hit over
             if (lane == 0)
@@ -996,7 +1124,7 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
                                                   ContactManifold *__restrict__ manifolds, const uint32_t *__restrict__ hit_counts,
                                                   uint32_t n_segments, uint32_t *__restrict__ next_hit_counts, const uint32_t *__restrict__ hits,
                                                   uint32_t segment_capacity, const unsigned long long *__restrict__ seeds,
-                                                  uint8_t *__restrict__ codes)
+                                                  uint8_t *__restrict__ codes, double *__restrict__ axis_cache)
 {
     __shared__ GjkLds s;
     for (uint32_t k = threadIdx.x; k < sizeof(s.ve) / 4; k += 64)
@@ -1005,14 +1133,14 @@ __global__ void __launch_bounds__(64) k_epa_pairs(BodyArrays b, PolytopeTables t
     const uint32_t n_hits = hit_list_open(prefix, hit_counts, n_segments, next_hit_counts, kHitSegments);
     for (uint32_t h = blockIdx.x; h < n_hits; h += gridDim.x) {
         const uint32_t p = hit_list_entry(prefix, n_segments, hits, segment_capacity, h);
-        epa_pair(s, b, t, frames, pairs, p, seeds[p], out, manifolds, codes, threadIdx.x);
+        epa_pair(s, b, t, frames, pairs, p, seeds[2 * (size_t)p], seeds[2 * (size_t)p + 1], out, manifolds, codes, axis_cache, threadIdx.x);
         __syncthreads(); // the next hit reuses the LDS
     }
 }
 
 } // namespace
 
-// seeds (8 bytes per pair), the segmented hit list (4 bytes per pair + one wave's worth of slack per segment), the overflow
+// seeds (16 bytes per pair), the segmented hit list (4 bytes per pair + one wave's worth of slack per segment), the overflow
 // list (4 bytes per pair) and its counter
 #ifdef XPBD_GJK_TIMING
 extern "C" int xpbd_debug_gjk_timing(unsigned long long out[8], int reset)
@@ -1028,7 +1156,7 @@ extern "C" int xpbd_debug_gjk_timing(unsigned long long out[8], int reset)
 }
 #endif
 
-size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 16 + (size_t)kHitSegments * 64 * 4 + 16; }
+size_t gjk_scratch_bytes(uint32_t n_pairs) { return (size_t)n_pairs * 24 + (size_t)kHitSegments * 64 * 4 + 16; }
 
 hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                 uint32_t n_pairs, GjkResult *out, ContactManifold *manifolds, GjkScratch &scratch, bool sphere_pretest,
@@ -1037,7 +1165,7 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     if (n_pairs == 0)
         return hipSuccess;
     unsigned long long *seeds = static_cast<unsigned long long *>(scratch.pairs_scratch);
-    uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + n_pairs);
+    uint32_t *hits = reinterpret_cast<uint32_t *>(seeds + 2 * (size_t)n_pairs);
     uint32_t *count = scratch.counters + (scratch.calls & 1u) * kHitSegments * kHitCounterStride;
     uint32_t *next = scratch.counters + ((scratch.calls + 1u) & 1u) * kHitSegments * kHitCounterStride;
     ++scratch.calls;
@@ -1089,19 +1217,19 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         if (t.max_face_verts <= 4) {
             const uint32_t groups = (n_pairs + 7) / 8;
             hipLaunchKernelGGL(k_epa_pairs_sub<8>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
-                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow, codes);
+                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow, codes, axis);
         } else {
             const uint32_t groups = (n_pairs + 3) / 4;
             hipLaunchKernelGGL(k_epa_pairs_sub<16>, dim3(groups < kEpaBlocks ? groups : kEpaBlocks), dim3(64), 0, stream, b, t, frames, pairs, out,
-                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow, codes);
+                               manifolds, count, next, hits, segment_capacity, seeds, overflow_count, overflow, codes, axis);
         }
         hipLaunchKernelGGL(k_epa_pairs, dim3(n_pairs < 256 ? n_pairs : 256), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds,
-                           overflow_count, 1u, next, overflow, n_pairs, seeds, codes);
+                           overflow_count, 1u, next, overflow, n_pairs, seeds, codes, axis);
         return hipGetLastError();
     }
     const uint32_t blocks = n_pairs < kEpaBlocks ? n_pairs : kEpaBlocks;
     hipLaunchKernelGGL(k_epa_pairs, dim3(blocks), dim3(64), 0, stream, b, t, frames, pairs, out, manifolds, count, kHitSegments, next, hits,
-                       segment_capacity, seeds, codes);
+                       segment_capacity, seeds, codes, axis);
     return hipGetLastError();
 }
 

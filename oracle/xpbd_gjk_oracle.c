@@ -19,7 +19,7 @@
 #include <math.h>
 #include <string.h>
 
-typedef struct { o_vec3 w, a, b; } mvert; /* w = a - b: a point of A (-) B with its two witnesses */
+typedef struct { o_vec3 w, a, b; uint32_t ia, ib; } mvert; /* w = a - b: a point of A (-) B with its two witnesses (and their vertex indices) */
 
 /* index of the LAST maximal dot(v, d) under the total order (Iterator::max_by + f64::total_cmp) */
 static uint32_t support_index(const o_vec3 *v, uint32_t n, o_vec3 d)
@@ -49,8 +49,10 @@ typedef struct {
 static mvert minkowski_support(const shapes_t *s, o_vec3 d)
 {
     mvert m;
-    m.a = s->wa[support_index(s->wa, s->na, d)];
-    m.b = s->wb[support_index(s->wb, s->nb, o_neg(d))];
+    m.ia = support_index(s->wa, s->na, d);
+    m.ib = support_index(s->wb, s->nb, o_neg(d));
+    m.a = s->wa[m.ia];
+    m.b = s->wb[m.ib];
     m.w = o_sub(m.a, m.b);
     return m;
 }
@@ -171,8 +173,73 @@ static int make_face(const mvert *v, uint32_t i0, uint32_t i1, uint32_t i2, uint
     return 1;
 }
 
-/* sep_dir (may be NULL): receives the direction whose support plane proved the pair separated, zero on every other exit */
-static void gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, o_vec3 *sep_dir, og_result *out)
+/*
+ * WARM START of the expansion (og_gjk_epa_cached): `warm` is the pair's cached direction -- the penetration normal of its last
+ * query, or the direction that separated it before it came into contact.  In a settled scene the next query's answer is a
+ * face of the Minkowski difference with (nearly) that normal, so the polytope is seeded with that face instead of GJK's
+ * tetrahedron: four support points in directions tilted away from n = warm / |warm| by OG_WARM_TILT towards the four
+ * diagonals of a tangent frame (t1 = normalize(n x e), e = the coordinate axis n has the least extent along, first minimum;
+ * t2 = n x t1), in the order (+t1 +t2), (-t1 +t2), (-t1 -t2), (+t1 -t2), duplicates (same vertex pair) dropped, plus the
+ * support point of -n as the apex.  With m = 3 or 4 distinct top points the polytope is the pyramid
+ *     top fan (0, k, k + 1), k = 1 .. m - 2 (opposite vertex: the apex m), then sides (k + 1, k, m), k = 0 .. m - 1 (indices of
+ *     the top modulo m; opposite vertex: top vertex k + 2),
+ * oriented by make_face.  It is used only if every face is sound, no vertex lies more than OG_WARM_CONVEX in front of any face
+ * (the five points are in convex position with exactly this face structure) and the origin is inside or on it (every face
+ * distance >= 0) -- which also proves the pair penetrating, so the boolean GJK is skipped.  Otherwise GJK runs as ever.  The
+ * expansion itself is unchanged, so it still ends on the globally closest face; for two boxes resting on each other it
+ * ends in its first iteration instead of the seventh.
+ */
+#define OG_WARM_TILT   1e-3
+#define OG_WARM_CONVEX 1e-10
+static int seed_polytope(const shapes_t *s, o_vec3 warm, mvert *v, eface *f, uint32_t *nv_out, uint32_t *nf_out)
+{
+    double len = o_magnitude(warm);
+    if (!(len > 0.0) || !(len <= DBL_MAX))
+        return 0;
+    o_vec3 n = o_scale(warm, 1.0 / len);
+    double ax = fabs(n.x), ay = fabs(n.y), az = fabs(n.z);
+    o_vec3 e = (ax <= ay && ax <= az) ? (o_vec3){ 1.0, 0.0, 0.0 } : (ay <= az ? (o_vec3){ 0.0, 1.0, 0.0 } : (o_vec3){ 0.0, 0.0, 1.0 });
+    o_vec3 t1 = o_normalize(o_cross(n, e)), t2 = o_cross(n, t1);
+    static const double sx[4] = { 1.0, -1.0, -1.0, 1.0 }, sy[4] = { 1.0, 1.0, -1.0, -1.0 };
+    uint32_t m = 0;
+    for (int k = 0; k < 4; k++) {
+        o_vec3 d = o_add(n, o_add(o_lscale(sx[k] * OG_WARM_TILT, t1), o_lscale(sy[k] * OG_WARM_TILT, t2)));
+        mvert p = minkowski_support(s, d);
+        int seen = 0;
+        for (uint32_t q = 0; q < m; q++)
+            seen |= v[q].ia == p.ia && v[q].ib == p.ib;
+        if (!seen)
+            v[m++] = p;
+    }
+    if (m < 3)
+        return 0;
+    mvert apex = minkowski_support(s, o_neg(n));
+    for (uint32_t q = 0; q < m; q++)
+        if (v[q].ia == apex.ia && v[q].ib == apex.ib)
+            return 0;
+    v[m] = apex;
+    uint32_t nf = 0;
+    for (uint32_t k = 1; k + 1 < m; k++)
+        if (!make_face(v, 0, k, k + 1, m, &f[nf++]))
+            return 0;
+    for (uint32_t k = 0; k < m; k++)
+        if (!make_face(v, (k + 1) % m, k, m, (k + 2) % m, &f[nf++]))
+            return 0;
+    for (uint32_t k = 0; k < nf; k++) {
+        if (!(f[k].dist >= 0.0))
+            return 0; /* the origin is outside (or the face is NaN) */
+        for (uint32_t q = 0; q <= m; q++)
+            if (!(o_dot(f[k].n, o_sub(v[q].w, v[f[k].i[0]].w)) <= OG_WARM_CONVEX))
+                return 0; /* not convex with this face structure */
+    }
+    *nv_out = m + 1;
+    *nf_out = nf;
+    return 1;
+}
+
+/* sep_dir (may be NULL): receives the direction whose support plane proved the pair separated, zero on every other exit.
+ * warm (zero = none): see seed_polytope. */
+static void gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, o_vec3 warm, o_vec3 *sep_dir, og_result *out)
 {
     shapes_t s;
     if (sep_dir)
@@ -188,49 +255,52 @@ static void gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polyto
     for (uint32_t k = 0; k < s.nb; k++)
         s.wb[k] = o_frame_mulv(fb, pb->vertices[k]);
 
-    /* ---- boolean GJK ---- */
-    mvert sx[4];
-    uint32_t n = 1;
-    o_vec3 d = o_sub(o_frame_mulv(fb, pb->centroid), o_frame_mulv(fa, pa->centroid));
-    if (!(o_dot(d, d) > 0.0))
-        d = (o_vec3){ 1.0, 0.0, 0.0 };
-    sx[0] = minkowski_support(&s, d);
-    d = o_neg(sx[0].w);
-    int hit = 0;
-    for (uint32_t it = 0; it < OG_MAX_GJK_ITERS; it++) {
-        out->gjk_iterations = it + 1;
-        if (!(o_dot(d, d) > 0.0)) { /* origin on the simplex: touching / degenerate */
-            out->status = OG_DEGENERATE;
-            return;
-        }
-        mvert p = minkowski_support(&s, d);
-        if (!(o_dot(p.w, d) > 0.0)) {
-            if (sep_dir)
-                *sep_dir = d;
-            return; /* the support plane does not pass the origin: separated (or just touching) */
-        }
-        sx[n++] = p;
-        if (do_simplex(sx, &n, &d)) {
-            hit = 1;
-            break;
-        }
-    }
-    if (!hit) {
-        out->status = OG_DEGENERATE; /* iteration cap: grazing configuration */
-        return;
-    }
-
-    /* ---- EPA ---- */
     mvert v[OG_MAX_EPA_VERTS];
     eface f[OG_MAX_EPA_FACES];
     uint32_t nv = 4, nf = 0;
-    memcpy(v, sx, sizeof(mvert) * 4);
-    static const uint32_t tet[4][3] = { {0, 1, 2}, {0, 3, 1}, {0, 2, 3}, {1, 3, 2} }; /* face k lacks vertex 3 - k */
-    for (int k = 0; k < 4; k++) /* the vertex opposite face k is 3 - k */
-        if (!make_face(v, tet[k][0], tet[k][1], tet[k][2], 3u - (uint32_t)k, &f[nf++])) {
-            out->status = OG_DEGENERATE; /* flat tetrahedron */
+    if (!seed_polytope(&s, warm, v, f, &nv, &nf)) {
+        /* ---- boolean GJK ---- */
+        mvert sx[4];
+        uint32_t n = 1;
+        o_vec3 d = o_sub(o_frame_mulv(fb, pb->centroid), o_frame_mulv(fa, pa->centroid));
+        if (!(o_dot(d, d) > 0.0))
+            d = (o_vec3){ 1.0, 0.0, 0.0 };
+        sx[0] = minkowski_support(&s, d);
+        d = o_neg(sx[0].w);
+        int hit = 0;
+        for (uint32_t it = 0; it < OG_MAX_GJK_ITERS; it++) {
+            out->gjk_iterations = it + 1;
+            if (!(o_dot(d, d) > 0.0)) { /* origin on the simplex: touching / degenerate */
+                out->status = OG_DEGENERATE;
+                return;
+            }
+            mvert p = minkowski_support(&s, d);
+            if (!(o_dot(p.w, d) > 0.0)) {
+                if (sep_dir)
+                    *sep_dir = d;
+                return; /* the support plane does not pass the origin: separated (or just touching) */
+            }
+            sx[n++] = p;
+            if (do_simplex(sx, &n, &d)) {
+                hit = 1;
+                break;
+            }
+        }
+        if (!hit) {
+            out->status = OG_DEGENERATE; /* iteration cap: grazing configuration */
             return;
         }
+
+        /* ---- EPA from GJK's tetrahedron ---- */
+        nv = 4, nf = 0;
+        memcpy(v, sx, sizeof(mvert) * 4);
+        static const uint32_t tet[4][3] = { {0, 1, 2}, {0, 3, 1}, {0, 2, 3}, {1, 3, 2} }; /* face k lacks vertex 3 - k */
+        for (int k = 0; k < 4; k++) /* the vertex opposite face k is 3 - k */
+            if (!make_face(v, tet[k][0], tet[k][1], tet[k][2], 3u - (uint32_t)k, &f[nf++])) {
+                out->status = OG_DEGENERATE; /* flat tetrahedron */
+                return;
+            }
+    }
     uint32_t best = 0;
     for (uint32_t it = 0; it < OG_MAX_EPA_ITERS; it++) {
         out->epa_iterations = it + 1;
@@ -317,7 +387,7 @@ static void gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polyto
 
 void og_gjk_epa(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, og_result *out)
 {
-    gjk_epa(fa, fb, pa, pb, NULL, out);
+    gjk_epa(fa, fb, pa, pb, (o_vec3){ 0.0, 0.0, 0.0 }, NULL, out);
 }
 
 /*
@@ -337,7 +407,9 @@ int og_direction_separates(o_frame fa, o_frame fb, const o_polytope *pa, const o
     return !(o_dot(o_sub(a, b), d) > 0.0);
 }
 
-/* og_gjk_epa behind that cache: *axis (zero = none) is consulted first and refreshed by every full query. */
+/* og_gjk_epa behind that cache: *axis (zero = none) is consulted first and refreshed by every full query -- with the
+ * direction that separates the pair, or with the penetration normal, which WARM-STARTS the pair's next expansion
+ * (seed_polytope); a degenerate query clears it. */
 void og_gjk_epa_cached(o_frame fa, o_frame fb, const o_polytope *pa, const o_polytope *pb, o_vec3 *axis, og_result *out)
 {
     if (o_dot(*axis, *axis) > 0.0 && og_direction_separates(fa, fb, pa, pb, *axis)) {
@@ -345,5 +417,7 @@ void og_gjk_epa_cached(o_frame fa, o_frame fb, const o_polytope *pa, const o_pol
         out->status = OG_SEPARATED;
         return;
     }
-    gjk_epa(fa, fb, pa, pb, axis, out);
+    gjk_epa(fa, fb, pa, pb, *axis, axis, out);
+    if (out->status == OG_PENETRATING)
+        *axis = out->normal;
 }

@@ -121,9 +121,11 @@ def test_random_convex_hulls_sat_equals_epa():
 def test_cached_separating_direction():
     """The pipeline's cache (og_gjk_epa_cached): a separated query leaves the direction that proved it, the next query of
     the pair tries that direction first.  It may only ever answer 'separated' for pairs that are separated (up to a
-    rounding-sized overlap), a penetrating pair clears it, and following a pair along a path it answers most queries."""
+    rounding-sized overlap); a penetrating query leaves its NORMAL, which warm-starts the next expansion (same depth and
+    normal as the cold query to rounding, see test_warm_started_expansion); following a pair along a path the cached
+    direction answers most queries."""
     rng = np.random.default_rng(21)
-    hits = queries = 0
+    hits = queries = warm = 0
     for _ in range(300):
         pa, pb = POLYS[rng.integers(3)], POLYS[rng.integers(3)]
         fa = (rng.uniform(-0.3, 0.3, 3), rand_quat(rng))
@@ -143,8 +145,58 @@ def test_cached_separating_direction():
                 m = ob.sat(fa, fb, pa, pb)
                 assert m.separated or max(m.query) > -1e-12
                 assert plain.status != ob.GJK_PENETRATING or plain.depth < 1e-12
-            else:                                                     # the full query: exactly the uncached result
+            elif cached.gjk_iterations:                               # the full query from GJK: exactly the uncached result
                 assert (cached.status, cached.gjk_iterations, cached.epa_iterations) == (plain.status, plain.gjk_iterations, plain.epa_iterations)
                 assert cached.depth == plain.depth
-                assert axis.any() == (plain.status == ob.GJK_SEPARATED)
-    assert hits > 0.3 * queries
+                assert axis.any() == (plain.status != ob.GJK_DEGENERATE)
+                if plain.status == ob.GJK_PENETRATING:
+                    assert np.array_equal(axis, plain.normal.np())
+            else:                                                     # the expansion was warm-started: the same answer to rounding
+                assert cached.status == ob.GJK_PENETRATING and had
+                assert plain.status == ob.GJK_PENETRATING and abs(cached.depth - plain.depth) < 1e-12
+                assert np.linalg.norm(cached.normal.np() - plain.normal.np()) < 1e-9
+                warm += 1
+    assert hits > 0.3 * queries and warm > 0
+
+
+def test_warm_started_expansion():
+    """seed_polytope: the pair's last penetration normal seeds the polytope with the face of the Minkowski difference that has
+    that normal.  (1) Boxes resting exactly on each other -- EPA's worst case: 3 GJK + 7 EPA iterations cold -- are answered
+    without GJK in ONE expansion step, with the same depth and normal.  (2) For random penetrating pairs followed over a small
+    motion the warm answer equals the cold one to rounding, whatever the cached direction was worth.  (3) A useless cached
+    direction (orthogonal to the contact) costs nothing but the attempt: the query falls back to GJK and is the cold one."""
+    cube = POLYS[0]
+    ident = np.array([1.0, 0.0, 0.0, 0.0])
+    for depth in (1e-5, 1e-3, 5e-2):
+        fa, fb = (np.zeros(3), ident), (np.array([0.0, 0.0, 1.0 - depth]), ident)
+        cold = ob.gjk_epa(fa, fb, cube, cube)
+        warm, axis = ob.gjk_epa_cached(fa, fb, cube, cube, np.array([0.0, 0.0, 1.0]))
+        assert (cold.status, cold.gjk_iterations, cold.epa_iterations) == (ob.GJK_PENETRATING, 3, 7)
+        assert (warm.status, warm.gjk_iterations, warm.epa_iterations) == (ob.GJK_PENETRATING, 0, 1)
+        assert abs(warm.depth - cold.depth) < 1e-15 and np.allclose(warm.normal.np(), [0.0, 0.0, 1.0], atol=1e-15)
+        assert np.array_equal(axis, warm.normal.np())
+        sideways, _ = ob.gjk_epa_cached(fa, fb, cube, cube, np.array([1.0, 0.0, 0.0]))       # (3): the pyramid does not hold the origin
+        assert (sideways.gjk_iterations, sideways.epa_iterations, sideways.depth) == (cold.gjk_iterations, cold.epa_iterations, cold.depth)
+    rng = np.random.default_rng(5)
+    seeded = total = saved = 0
+    for _ in range(1500):
+        pa, pb = POLYS[rng.integers(3)], POLYS[rng.integers(3)]
+        fa = (rng.uniform(-0.1, 0.1, 3), rand_quat(rng))
+        fb = (rng.uniform(-0.6, 0.6, 3), rand_quat(rng))
+        first = ob.gjk_epa(fa, fb, pa, pb)
+        if first.status != ob.GJK_PENETRATING:
+            continue
+        q = fb[1] + rng.normal(scale=1e-3, size=4)
+        fb = (fb[0] + rng.normal(scale=1e-3, size=3), q / np.linalg.norm(q))
+        cold = ob.gjk_epa(fa, fb, pa, pb)
+        warm, axis = ob.gjk_epa_cached(fa, fb, pa, pb, first.normal.np())
+        assert warm.status == cold.status
+        if cold.status != ob.GJK_PENETRATING:
+            continue
+        total += 1
+        seeded += warm.gjk_iterations == 0
+        saved += (cold.gjk_iterations + cold.epa_iterations) - (warm.gjk_iterations + warm.epa_iterations)
+        assert abs(warm.depth - cold.depth) < 1e-12 and np.linalg.norm(warm.normal.np() - cold.normal.np()) < 1e-9
+        m = ob.sat(fa, fb, pa, pb)                                                           # ... and both equal the exact SAT
+        assert not m.separated and abs(-max(m.query) - warm.depth) < 1e-6 + 1e-9
+    assert total > 500 and seeded > 0.2 * total and saved > 0
