@@ -300,6 +300,9 @@ __device__ __forceinline__ unsigned long long pack_seed(const MVert &s0, const M
 // of the pyramid over m = 3 or 4 top points: the top fan (0, f + 1, f + 2) for f < m - 2 (opposite vertex: the apex m), then the
 // sides ((k + 1) % m, k, m), k = f - (m - 2) (opposite vertex: (k + 2) % m).
 constexpr double kWarmTilt = 1e-3, kWarmConvex = 1e-10;
+#ifndef XPBD_GJK_WARM_MODE
+#define XPBD_GJK_WARM_MODE 1 // 0: an A/B build that never warm-starts (it does NOT match the oracle)
+#endif
 // (i0 | i1 << 8 | i2 << 16 | opposite << 24)
 __device__ __forceinline__ uint32_t warm_face_indices(uint32_t f, uint32_t m)
 {
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
     // warm start: the pair's cached direction seeds the polytope and, if the seed holds, replaces the boolean GJK
     unsigned long long seed_word1 = 0;
     bool seeded = false;
-    if (usable && axis_cache) {
+    if (XPBD_GJK_WARM_MODE != 0 && usable && axis_cache) {
         const double *c = axis_cache + 3 * (size_t)p;
         const Vec3 warm{c[0], c[1], c[2]};
         if (dot(warm, warm) > 0.0) { // group-uniform

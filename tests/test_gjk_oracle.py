@@ -174,7 +174,7 @@ def test_warm_started_expansion():
         assert (cold.status, cold.gjk_iterations, cold.epa_iterations) == (ob.GJK_PENETRATING, 3, 7)
         assert (warm.status, warm.gjk_iterations, warm.epa_iterations) == (ob.GJK_PENETRATING, 0, 1)
         assert abs(warm.depth - cold.depth) < 1e-15 and np.allclose(warm.normal.np(), [0.0, 0.0, 1.0], atol=1e-15)
-        assert np.array_equal(axis, warm.normal.np())
+        assert np.array_equal(axis, warm.normal.np())                                       # one step: keep warm-starting
         sideways, _ = ob.gjk_epa_cached(fa, fb, cube, cube, np.array([1.0, 0.0, 0.0]))       # (3): the pyramid does not hold the origin
         assert (sideways.gjk_iterations, sideways.epa_iterations, sideways.depth) == (cold.gjk_iterations, cold.epa_iterations, cold.depth)
     rng = np.random.default_rng(5)
