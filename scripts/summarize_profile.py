@@ -169,6 +169,31 @@ def main(out):
                 contacts.setdefault(scene, {})[k] = row
     if contacts:
         s["contacts_traffic"] = contacts
+        # HBM-side bytes of ONE SUBSTEP of each contact scene: its per-substep kernels at (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the
+        # factor 2 holds for gathered 16-byte loads as well: profiles/r03_c_fetch_calibration.json), weighted by how often a
+        # substep launches them (19 of 20 substeps end in the fused kernel, the last in k_pair_solve_derive; k_integrate_ground
+        # opens the frame)
+        names = {"stacks": "stacks_262144_sat", "mixed_sat": "mixed_pile_65536_sat", "boxes_pile": "boxes_pile_262144_sat",
+                 "stacks_gjk": "stacks_262144_gjk_epa", "mixed_gjk": "mixed_pile_65536_gjk_epa", "joints": "boxes_262144_joints_65536"}
+        per_substep = {}
+        for scene, ks in contacts.items():
+            total, parts = 0.0, {}
+            for k, row in ks.items():
+                if k.startswith("k_pair_solve_integrate_ground"):
+                    w = 19.0 / 20.0
+                elif k.startswith("k_pair_solve_derive") or k.startswith("k_integrate_ground"):
+                    w = 1.0 / 20.0
+                elif k.startswith(("k_sat_", "k_pair_pretest", "k_gjk_pairs", "k_epa_pairs")):
+                    w = 1.0
+                else:
+                    continue
+                parts[k] = w * row["bytes_per_launch_factor_2"]
+                total += parts[k]
+            per_substep[names[scene]] = {"bytes_per_substep": total, "kernels": parts,
+                                         "source": "profiles/%s_summary.json contacts_traffic (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate "
+                                                   "passes of `bench.py --steps 20 --warmup 5 --only <sub-result>`, last 400 launches of each kernel; "
+                                                   "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, calibrated for gathers in profiles/r03_c_fetch_calibration.json)" % tag}
+        s["contacts_traffic_per_substep"] = per_substep
     print(json.dumps(s, indent=1))
 
 
