@@ -83,4 +83,5 @@ if has contacts_pmc; then
 fi
 python3 scripts/summarize_profile.py "$OUT" > "$OUT/summary.json"
 find "$OUT" -name '*kernel_trace.csv' -delete      # the raw traces (tens of MB each) stay on the box
+find "$OUT" -name '*counter_collection.csv' -size +2M -delete   # ... and so do the large raw counter tables (gpurun copies back <= 64 MiB)
 cat "$OUT/summary.json"

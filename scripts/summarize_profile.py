@@ -169,30 +169,44 @@ def main(out):
                 contacts.setdefault(scene, {})[k] = row
     if contacts:
         s["contacts_traffic"] = contacts
-        # HBM-side bytes of ONE SUBSTEP of each contact scene: its per-substep kernels at (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the
-        # factor 2 holds for gathered 16-byte loads as well: profiles/r03_c_fetch_calibration.json), weighted by how often a
-        # substep launches them (19 of 20 substeps end in the fused kernel, the last in k_pair_solve_derive; k_integrate_ground
-        # opens the frame)
+        # HBM-side bytes of ONE SUBSTEP of each contact scene in its TIMED regime: every dispatch of the last frames of the run
+        # (the automatic SAT schedule may use other kernels during the pre-roll) at (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- the
+        # factor 2 holds for gathered 16-byte loads as well: profiles/r03_c_fetch_calibration.json -- summed and divided by the
+        # number of substeps among them (one per-body kernel launch = one substep); the once-per-frame broadphase is left out
         names = {"stacks": "stacks_262144_sat", "mixed_sat": "mixed_pile_65536_sat", "boxes_pile": "boxes_pile_262144_sat",
                  "stacks_gjk": "stacks_262144_gjk_epa", "mixed_gjk": "mixed_pile_65536_gjk_epa", "joints": "boxes_262144_joints_65536"}
         per_substep = {}
-        for scene, ks in contacts.items():
-            total, parts = 0.0, {}
-            for k, row in ks.items():
-                if k.startswith("k_pair_solve_integrate_ground"):
-                    w = 19.0 / 20.0
-                elif k.startswith("k_pair_solve_derive") or k.startswith("k_integrate_ground"):
-                    w = 1.0 / 20.0
-                elif k.startswith(("k_sat_", "k_pair_pretest", "k_gjk_pairs", "k_epa_pairs")):
-                    w = 1.0
-                else:
-                    continue
-                parts[k] = w * row["bytes_per_launch_factor_2"]
-                total += parts[k]
-            per_substep[names[scene]] = {"bytes_per_substep": total, "kernels": parts,
-                                         "source": "profiles/%s_summary.json contacts_traffic (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate "
-                                                   "passes of `bench.py --steps 20 --warmup 5 --only <sub-result>`, last 400 launches of each kernel; "
-                                                   "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, calibrated for gathers in profiles/r03_c_fetch_calibration.json)" % tag}
+
+        def tail_bytes(name, counter, scale):
+            rows = rows_of(os.path.join(out, "pmc_" + name, "**", "*_counter_collection.csv"))
+            rows = [r for r in rows if r["Counter_Name"] == counter]
+            if not rows:
+                return None, 0, {}
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            bodies = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("k_pair_solve_")]
+            if len(bodies) < 200:
+                return None, 0, {}
+            first = bodies[-200]                       # the last 200 substeps = the last 10 frames
+            start = first
+            while start > 0 and not short(rows[start - 1]["Kernel_Name"]).startswith("k_pair_solve_"):
+                start -= 1                             # ... from the narrowphase launches in front of their first per-body kernel
+            per = collections.defaultdict(float)
+            for r in rows[start:]:
+                k = short(r["Kernel_Name"])
+                if k.startswith(("k_sat_", "k_pair_", "k_gjk_pairs", "k_epa_pairs", "k_integrate_ground")):
+                    per[k] += float(r["Counter_Value"]) * 1024.0 * scale
+            return sum(per.values()) / 200.0, 200, {k: v / 200.0 for k, v in per.items()}
+        for scene in contacts:
+            fb, n1, fk = tail_bytes("fetch_" + scene, "FETCH_SIZE", 2.0)
+            wb, n2, wk = tail_bytes("write_" + scene, "WRITE_SIZE", 1.0)
+            if fb is None or wb is None:
+                continue
+            per_substep[names[scene]] = {"bytes_per_substep": fb + wb, "read_bytes_per_substep": fb, "written_bytes_per_substep": wb,
+                                         "kernels_bytes_per_substep": {k: fk.get(k, 0.0) + wk.get(k, 0.0) for k in sorted(set(fk) | set(wk))},
+                                         "substeps_averaged": 200,
+                                         "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py "
+                                                   "--steps 20 --warmup 5 --only <sub-result>`, the dispatches of the last 200 substeps; bytes = "
+                                                   "(2*FETCH_SIZE + WRITE_SIZE)*1024, calibrated for gathers in profiles/r03_c_fetch_calibration.json)" % tag}
         s["contacts_traffic_per_substep"] = per_substep
     print(json.dumps(s, indent=1))
 
