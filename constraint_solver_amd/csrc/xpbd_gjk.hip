@@ -817,13 +817,22 @@ __device__ __forceinline__ void epa_pair(GjkLds &s, const BodyArrays &b, const P
 __device__ __forceinline__ uint32_t hit_list_open(uint32_t *prefix, const uint32_t *__restrict__ counts, uint32_t n_segments,
                                                   uint32_t *__restrict__ next_counts, uint32_t n_next)
 {
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < n_segments; ++k) {
-            prefix[k] = run;
-            run += counts[k * kHitCounterStride];
+    static_assert(kHitSegments <= 64, "one segment counter per lane of the first wave");
+    if (threadIdx.x < 64) {
+        // one counter per lane and a shuffle scan: ONE round trip to memory (a loop on thread 0 paid one dependent load per segment
+        // before a block could start)
+        const uint32_t lane = threadIdx.x;
+        const uint32_t mine = lane < n_segments ? counts[lane * kHitCounterStride] : 0u;
+        uint32_t run = mine;
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(run, off, 64);
+            if (lane >= off)
+                run += up;
         }
-        prefix[n_segments] = run;
+        if (lane < n_segments)
+            prefix[lane] = run - mine; // exclusive
+        if (lane == 63)
+            prefix[n_segments] = run;
     }
     if (blockIdx.x == 0 && threadIdx.x < n_next)
         next_counts[threadIdx.x * kHitCounterStride] = 0;
