@@ -526,10 +526,11 @@ class MultiWorld:
 
     def plan_stats(self):
         """dict: plans, frames undone, bodies that changed owner at the last plan, fewest / most bodies owned by a rank, step
-        calls and the host nanoseconds inside them (enqueueing, waiting for the pair counts, waiting for the frame's end)."""
+        calls and the host nanoseconds inside them (enqueueing, waiting for the pair counts, waiting for the frame's end), and the
+        host nanoseconds spent in plans (creation, re-plans)."""
         out = (C.c_uint64 * 10)()
         _check(hip_lib().xpbd_multi_world_plan_stats(self._h, out))
-        keys = ("plans", "rollbacks", "migrated", "owned_min", "owned_max", "steps", "ns_enqueue", "ns_wait_broadphase", "ns_wait_frame")
+        keys = ("plans", "rollbacks", "migrated", "owned_min", "owned_max", "steps", "ns_enqueue", "ns_wait_broadphase", "ns_wait_frame", "ns_plan")
         return dict(zip(keys, (int(x) for x in out)))
 
     def owners(self):

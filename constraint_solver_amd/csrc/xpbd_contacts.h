@@ -124,6 +124,15 @@ hipError_t launch_snapshot_positions(const BodyArrays &b, const uint32_t *indice
 hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices, uint32_t n, const double *snapshot, const double *scale,
                                     double *out, hipStream_t stream);
 
+// Re-planning the multi-GPU world on the device.  keys[k] = grid cell (xpbd_halo_cell_key, same bits) of body indices[k]
+// (indices == NULL: body k), *bad = min(*bad, first list index with a non-finite centre);  out[k] = the 38 doubles of
+// xpbd_rigid of body indices[k] + its shape id as a double;  new world (AoS + shape ids) from src[s] >= 0: slot of the old
+// world's AoS copy, < 0: incoming record -src[s] - 1 (39 doubles each).
+hipError_t launch_cell_keys(const BodyArrays &b, const uint32_t *indices, uint32_t n, double edge, int64_t *keys, uint32_t *bad, hipStream_t stream);
+hipError_t launch_gather_records(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *out, hipStream_t stream);
+hipError_t launch_repack_bodies(const double *old_aos, const uint32_t *old_shape, const int32_t *src, uint32_t n_new, const double *incoming,
+                                double *new_aos, uint32_t *new_shape, hipStream_t stream);
+
 // Exclusive scan of data[0..n) in place; data[n] receives the total.  scratch: >= n/1024 + 2 uint32.
 hipError_t launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *scratch, hipStream_t stream);
 

@@ -1117,6 +1117,87 @@ __global__ void __launch_bounds__(kBlock) k_max_displacement2(BodyArrays b, cons
     }
 }
 
+// ---- re-planning the multi-GPU world without a host round trip of the bodies (xpbd_multi.cpp) --------------------------------
+// The grid cell of the bounding-sphere centre (position + center_of_mass, as the host planner adds them) of the listed
+// bodies: the same floor(c / edge), clamp and packing as xpbd_halo_cell_key, so the same bits.  *bad = the smallest list
+// index with a non-finite centre (UINT32_MAX: none).
+constexpr long long kHaloCellBias = 1ll << 20, kHaloCellLimit = kHaloCellBias - 4;
+
+__device__ __forceinline__ long long halo_clamp_cell(double q)
+{
+    const double lim = (double)kHaloCellLimit;
+    if (!(q >= -lim)) // NaN or far negative
+        return -kHaloCellLimit;
+    return q > lim ? kHaloCellLimit : (long long)q;
+}
+
+__global__ void k_cell_keys(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n, double edge, long long *__restrict__ keys,
+                            uint32_t *__restrict__ bad)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    const uint32_t i = indices ? indices[k] : k;
+    const Vec3 p = load3(b.dyn, D_POS, b.stride, i), com = load3(b.stat, S_COM, b.stride, i);
+    const double c[3] = {p.x + com.x, p.y + com.y, p.z + com.z};
+    long long cell[3];
+    bool finite = true;
+    for (int a = 0; a < 3; ++a) {
+        finite = finite && fabs(c[a]) <= DBL_MAX;
+        cell[a] = halo_clamp_cell(floor(c[a] / edge));
+    }
+    if (!finite)
+        atomicMin(bad, k);
+    keys[k] = ((cell[0] + kHaloCellBias) << 42) | ((cell[1] + kHaloCellBias) << 21) | (cell[2] + kHaloCellBias);
+}
+
+__device__ __forceinline__ uint32_t aos_slot_of_field(uint32_t f) // xpbd_rigid double index of SoA field f (dyn first, then stat)
+{
+    if (f < kDynFields) // pos 31-33, rot 34-37, vel 22-24, ang 25-27
+        return f < 7 ? 31 + f : (f < 10 ? 22 + (f - 7) : 25 + (f - 10));
+    const uint32_t g = f - kDynFields; // 0..21 identical; com 28-30
+    return g < 22 ? g : 28 + (g - 22);
+}
+
+// out[k] = {xpbd_rigid of body indices[k] (38 doubles), its shape id as a double}: the plan-time record of a body
+__global__ void k_gather_records(BodyArrays b, const uint32_t *__restrict__ indices, uint32_t n, double *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t kFields = kDynFields + kStatFields;
+    if (t >= n * (kFields + 1))
+        return;
+    const uint32_t k = t / (kFields + 1), f = t - k * (kFields + 1), i = indices[k];
+    double *rec = out + (size_t)k * (kFields + 1);
+    if (f == kFields)
+        rec[kFields] = (double)b.shape_id[i];
+    else
+        rec[aos_slot_of_field(f)] = f < kDynFields ? b.dyn[(size_t)f * b.stride + i] : b.stat[(size_t)(f - kDynFields) * b.stride + i];
+}
+
+// The bodies of a new local world in AoS: body s comes from slot src[s] of the old world's AoS copy (src[s] >= 0) or is
+// incoming record -src[s] - 1 (39 doubles each: xpbd_rigid + shape id).
+__global__ void k_repack_bodies(const double *__restrict__ old_aos, const uint32_t *__restrict__ old_shape, const int32_t *__restrict__ src,
+                                uint32_t n_new, const double *__restrict__ incoming, double *__restrict__ new_aos,
+                                uint32_t *__restrict__ new_shape)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t kFields = kDynFields + kStatFields;
+    if (t >= (size_t)n_new * kFields)
+        return;
+    const uint32_t s = (uint32_t)(t / kFields), f = (uint32_t)(t - (size_t)s * kFields);
+    const int32_t from = src[s];
+    if (from >= 0) {
+        new_aos[t] = old_aos[(size_t)from * kFields + f];
+        if (f == 0)
+            new_shape[s] = old_shape[from];
+    } else {
+        const double *rec = incoming + (size_t)(-(from + 1)) * (kFields + 1);
+        new_aos[t] = rec[f];
+        if (f == 0)
+            new_shape[s] = (uint32_t)rec[kFields];
+    }
+}
+
 uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 } // namespace
@@ -1280,6 +1361,31 @@ hipError_t launch_max_displacement2(const BodyArrays &b, const uint32_t *indices
 {
     if (n)
         hipLaunchKernelGGL(k_max_displacement2, dim3(blocks_for(n)), dim3(kBlock), 0, stream, b, indices, n, snapshot, scale, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_cell_keys(const BodyArrays &b, const uint32_t *indices, uint32_t n, double edge, int64_t *keys, uint32_t *bad, hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n)), dim3(kBlock), 0, stream, b, indices, n, edge, reinterpret_cast<long long *>(keys), bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_records(const BodyArrays &b, const uint32_t *indices, uint32_t n, double *out, hipStream_t stream)
+{
+    if (n)
+        hipLaunchKernelGGL(k_gather_records, dim3(blocks_for(n * (kDynFields + kStatFields + 1))), dim3(kBlock), 0, stream, b, indices, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_repack_bodies(const double *old_aos, const uint32_t *old_shape, const int32_t *src, uint32_t n_new, const double *incoming,
+                                double *new_aos, uint32_t *new_shape, hipStream_t stream)
+{
+    if (n_new) {
+        const size_t threads = (size_t)n_new * (kDynFields + kStatFields);
+        hipLaunchKernelGGL(k_repack_bodies, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, old_aos, old_shape, src, n_new,
+                           incoming, new_aos, new_shape);
+    }
     return hipGetLastError();
 }
 

@@ -48,4 +48,13 @@ int frame_snapshot_restore(xpbd_world *w);
 int halo_substep_boundary(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
 int halo_substep_interior(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
 int halo_substep_ghosts(xpbd_world *w, double h, uint32_t k, bool last, const HaloLists &l);
+// ---- a plan of the multi-GPU world with the bodies staying on the device -----------------------------------------------------
+// host_keys[k] = grid cell (xpbd_halo_cell_key: same bits) of the bounding-sphere centre of body dev_slots[k] (a device array;
+// NULL: body k); *bad_index = first k whose centre is not finite (UINT32_MAX: none).  Synchronous.
+int halo_cell_keys(xpbd_world *w, const uint32_t *dev_slots, uint32_t n, double edge, int64_t *host_keys, uint32_t *bad_index);
+// out39[k] = the xpbd_rigid of body host_slots[k] (38 doubles) and its shape id as a double.  Synchronous.
+int download_records(xpbd_world *w, const uint32_t *host_slots, uint32_t n, double *out39);
+// The world's bodies become: body s = the present body host_src[s] (>= 0) or incoming record -host_src[s] - 1 (39 doubles
+// each).  Only the incoming records cross the bus; otherwise as xpbd_world_upload_bodies (joints and neighbour lists dropped).
+int repack_bodies(xpbd_world *w, const int32_t *host_src, uint32_t n_new, const double *incoming39, uint32_t n_incoming);
 } // namespace xpbd

@@ -37,6 +37,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -255,16 +256,11 @@ struct HaloPlanner {
                    std::vector<uint32_t> &boundary, std::vector<uint8_t> *far = nullptr) const
     {
         own.clear();
-        for (uint32_t g = 0; g < n; ++g)
-            if (owner[g] == rank)
-                own.push_back(g);
-        const uint32_t n_own = (uint32_t)own.size();
-        // this rank's unique cells and their bounding box
-        std::unordered_map<int64_t, uint8_t> own_cells; // cell -> some other rank owns a body within one cell of it
-        own_cells.reserve((size_t)n_own / 2 + 16);
+        // this rank's bodies and the bounding box of their cells
         int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
-        for (uint32_t g : own)
-            if (own_cells.emplace(keys[g], 0).second) {
+        for (uint32_t g = 0; g < n; ++g)
+            if (owner[g] == rank) {
+                own.push_back(g);
                 int64_t c[3];
                 cell_of_key(keys[g], c);
                 for (int a = 0; a < 3; ++a) {
@@ -272,9 +268,19 @@ struct HaloPlanner {
                     hi[a] = std::max(hi[a], c[a]);
                 }
             }
-        // the foreign bodies within two cells of that box: their cells, and (within one cell of an own cell) the ghosts
+        const uint32_t n_own = (uint32_t)own.size();
+        // the foreign bodies within two cells of that box: their cells, and (within one cell of the box) the possible ghosts.
+        // `layers[a]`: per coordinate of the box along axis a, is there a foreign cell?  Along the axis the slabs are cut across
+        // only the ends of the box have any, and own bodies more than two layers from such a coordinate -- nearly all of a
+        // slab -- need no hashing at all.
+        std::vector<uint8_t> layers[3];
+        int64_t layer0[3] = {0, 0, 0};
+        for (int a = 0; a < 3 && n_own; ++a) {
+            layer0[a] = lo[a] - 4;
+            layers[a].assign((size_t)(hi[a] - lo[a] + 9), 0);
+        }
         std::unordered_set<int64_t> foreign_cells;
-        std::vector<uint32_t> candidates; // foreign bodies inside the box grown by one cell: the possible ghosts
+        std::vector<uint32_t> candidates;
         for (uint32_t g = 0; g < n && n_own; ++g) {
             if (owner[g] == rank)
                 continue;
@@ -288,24 +294,60 @@ struct HaloPlanner {
             if (!in2)
                 continue;
             foreign_cells.insert(keys[g]);
+            for (int a = 0; a < 3; ++a)
+                layers[a][(size_t)(c[a] - layer0[a])] = 1;
             if (in1)
                 candidates.push_back(g);
         }
-        // per own cell: a foreign body within one cell?  (then all its bodies are boundary bodies)
-        for (auto &cell : own_cells) {
-            int64_t c[3];
-            cell_of_key(cell.first, c);
-            bool seen = false;
-            for (int dx = -1; dx <= 1 && !seen; ++dx)
-                for (int dy = -1; dy <= 1 && !seen; ++dy)
-                    for (int dz = -1; dz <= 1 && !seen; ++dz)
-                        seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
-            cell.second = seen;
+        // near1 / near2 [x]: a foreign cell within one / two layers of layer x, along the axis that leaves the smallest share
+        // of the box near foreign layers
+        int major = 0;
+        std::vector<uint8_t> near1, near2;
+        double best = 2.0;
+        for (int a = 0; a < 3 && n_own; ++a) {
+            std::vector<uint8_t> n1(layers[a].size(), 0), n2(layers[a].size(), 0);
+            size_t marked = 0;
+            for (size_t x = 0; x < layers[a].size(); ++x) {
+                for (int d = -2; d <= 2; ++d) {
+                    const size_t y = x + (size_t)(d + 2);
+                    if (y < 2 || y - 2 >= layers[a].size() || !layers[a][y - 2])
+                        continue;
+                    n2[x] = 1;
+                    if (d >= -1 && d <= 1)
+                        n1[x] = 1;
+                }
+                marked += n2[x] && x >= 4 && x < layers[a].size() - 4;
+            }
+            const double share = (double)marked / (double)(hi[a] - lo[a] + 1);
+            if (share < best) {
+                best = share;
+                major = a;
+                near1.swap(n1);
+                near2.swap(n2);
+            }
         }
+        const int64_t layer_base = layer0[major];
+        // this rank's cells next to foreign layers (the rim): per cell, is a foreign body within one cell?  (then all its
+        // bodies are boundary bodies)
+        std::unordered_map<int64_t, uint8_t> rim_cells;
         std::vector<uint8_t> is_boundary(n_own, 0);
-        for (uint32_t k = 0; k < n_own; ++k)
-            is_boundary[k] = own_cells.find(keys[own[k]])->second;
-        // a candidate is a ghost iff an own cell lies within one cell of its cell
+        for (uint32_t k = 0; k < n_own; ++k) {
+            int64_t c[3];
+            cell_of_key(keys[own[k]], c);
+            if (!near1[(size_t)(c[major] - layer_base)])
+                continue;
+            auto it = rim_cells.find(keys[own[k]]);
+            if (it == rim_cells.end()) {
+                bool seen = false;
+                for (int dx = -1; dx <= 1 && !seen; ++dx)
+                    for (int dy = -1; dy <= 1 && !seen; ++dy)
+                        for (int dz = -1; dz <= 1 && !seen; ++dz)
+                            seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
+                it = rim_cells.emplace(keys[own[k]], seen).first;
+            }
+            is_boundary[k] = it->second;
+        }
+        // a candidate is a ghost iff an own cell lies within one cell of its cell (such an own cell is a rim cell)
         std::unordered_map<int64_t, uint8_t> reached; // foreign cell -> within one cell of an own cell (memoised)
         std::vector<uint32_t> ghost_list;
         for (uint32_t g : candidates) {
@@ -317,7 +359,7 @@ struct HaloPlanner {
                 for (int dx = -1; dx <= 1 && !near; ++dx)
                     for (int dy = -1; dy <= 1 && !near; ++dy)
                         for (int dz = -1; dz <= 1 && !near; ++dz)
-                            near = own_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
+                            near = rim_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
                 it = reached.emplace(keys[g], near).first;
             }
             if (it->second)
@@ -342,22 +384,29 @@ struct HaloPlanner {
             if (is_boundary[k])
                 boundary.push_back(own[k]);
         if (far) {
-            // dilate the nearby foreign cells by two cells; an own body outside that set (and not a boundary body) is far
+            // an own body with a foreign cell within two cells of its own (or a boundary body) is not far
             far->assign(n_own, 0);
-            const size_t limit = 20000; // beyond that many foreign cells around the slab the dilation is not worth it: nobody is far
+            const size_t limit = 20000; // beyond that many foreign cells around the slab the test is not worth it: nobody is far
             if (n_own && foreign_cells.size() <= limit) {
-                std::unordered_set<int64_t> near_cells;
-                near_cells.reserve(foreign_cells.size() * 40 + 16);
-                for (int64_t key : foreign_cells) {
+                std::unordered_map<int64_t, uint8_t> near_cells; // own cell in a layer near foreign ones -> a foreign cell within two cells
+                for (uint32_t k = 0; k < n_own; ++k) {
                     int64_t c[3];
-                    cell_of_key(key, c);
-                    for (int dx = -2; dx <= 2; ++dx)
-                        for (int dy = -2; dy <= 2; ++dy)
-                            for (int dz = -2; dz <= 2; ++dz)
-                                near_cells.insert(cell_key(c[0] + dx, c[1] + dy, c[2] + dz));
+                    cell_of_key(keys[own[k]], c);
+                    if (!near2[(size_t)(c[major] - layer_base)]) {
+                        (*far)[k] = !is_boundary[k];
+                        continue;
+                    }
+                    auto it = near_cells.find(keys[own[k]]);
+                    if (it == near_cells.end()) {
+                        bool seen = false;
+                        for (int dx = -2; dx <= 2 && !seen; ++dx)
+                            for (int dy = -2; dy <= 2 && !seen; ++dy)
+                                for (int dz = -2; dz <= 2 && !seen; ++dz)
+                                    seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
+                        it = near_cells.emplace(keys[own[k]], seen).first;
+                    }
+                    (*far)[k] = !it->second && !is_boundary[k];
                 }
-                for (uint32_t k = 0; k < n_own; ++k)
-                    (*far)[k] = !near_cells.count(keys[own[k]]) && !is_boundary[k];
             }
         }
     }
@@ -372,10 +421,10 @@ struct Shard {
     ncclComm_t comm = nullptr;
     hipEvent_t ev_send = nullptr, ev_recv = nullptr; // in-process transport
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr; // world stream -> communication stream -> world stream
-    // The bodies this shard HOLDS (host copies): before the first plan the index slice the caller handed over, after a plan
-    // the bodies it owns.  Ascending global ids, kRigid doubles each, shape ids.  Refreshed from the device by fetch_owned.
-    std::vector<uint32_t> held_ids, held_sid;
-    std::vector<double> held;
+    // The bodies this shard HOLDS (global ids, ascending): before the first plan the index slice the caller handed over,
+    // after a plan the bodies it owns.  Their state lives in the shard's world on the device (slot owned_slots_h[i]) and
+    // stays there through re-plans.
+    std::vector<uint32_t> held_ids;
     // plan
     std::vector<uint32_t> local_ids, ghosts, boundary; // global ids (ascending): owned + ghost bodies; ghosts; mirrored owned bodies
     std::vector<uint32_t> owned_slots_h;               // local slot of held_ids[i]
@@ -442,8 +491,10 @@ struct xpbd_multi_world {
     std::vector<xpbd_joint> joints;
     std::vector<uint8_t> owner;        // [n_global] as of the last plan
     std::vector<uint32_t> owned_count; // [n_ranks]
-    uint64_t plans = 0, rollbacks = 0, migrated = 0, steps = 0, ns_enqueue = 0, ns_wait_broadphase = 0, ns_wait_frame = 0;
+    uint64_t plans = 0, rollbacks = 0, migrated = 0, steps = 0, ns_enqueue = 0, ns_wait_broadphase = 0, ns_wait_frame = 0, ns_plan = 0;
     double cell_edge = 0.0;
+    double rmax_local = 0.0;          // largest bounding radius (r_shape + |centroid - com|) among the bodies this process handed over
+    std::vector<int32_t> slot_of;     // [n_global] scratch of a plan: local slot of a body, -1 outside the shard being built
     double last_displacement = 0.0; // the largest fraction of its travel allowance any body had used at the last check, times halo_margin
     Workers *workers = nullptr;     // one enqueueing thread per local shard (n_local > 1), started by the first step
     bool all_local() const { return shards.size() == n_ranks; }
@@ -645,49 +696,41 @@ int upload_vector(DevBuf &buf, const std::vector<T> &v, hipStream_t stream)
 
 struct KeyRow {
     int64_t key;
-    uint32_t id, sid;
+    uint32_t id, unused;
 };
 
-// Builds ownership and halos from the bodies the shards hold (Shard::held*) and uploads every shard's local world.
-// Collective.  Local failures are carried through the collectives (LocalStatus), so all ranks fail together.
-int make_plan(xpbd_multi_world *mw)
+// Builds ownership and halos from the bodies the shards own AT THE MOMENT (the first time: the index slices the caller handed
+// over, uploaded as they are) and re-packs every shard's local world.  The bodies stay on the device: what crosses the bus
+// is 8 bytes of cell key per owned body, the records of the bodies that change hands or are mirrored (a few per cent) and
+// the index lists of the new plan.  Collective.  Local failures are carried through the collectives (LocalStatus: `st` may
+// already hold one), so all ranks fail together.
+int make_plan(xpbd_multi_world *mw, LocalStatus &st)
 {
     const uint32_t n = mw->n_global, w = mw->n_ranks;
     const size_t n_local = mw->shards.size();
-    LocalStatus st;
     std::vector<uint8_t> gathered;
     std::vector<const void *> send(n_local);
+    const uint64_t t_plan = now_ns();
+    // XPBD_MULTI_TRACE_PLAN=1: the host time of every phase of a plan on stderr
+    static const bool trace = std::getenv("XPBD_MULTI_TRACE_PLAN") != nullptr;
+    uint64_t t_lap = t_plan;
+    auto lap = [&](const char *what) {
+        if (trace) {
+            const uint64_t t = now_ns();
+            std::fprintf(stderr, "[xpbd plan %llu] %-28s %8.3f ms\n", (unsigned long long)mw->plans, what, (double)(t - t_lap) * 1e-6);
+            t_lap = t;
+        }
+    };
 
-    // 1. bounding spheres of the held bodies (centre = position + center_of_mass, radius = r_shape + |centroid - com|:
-    //    conservative whatever the rotation), the largest radius of the whole world and how many bodies every rank holds
-    std::vector<std::vector<double>> centre(n_local);
+    // 1. the largest bounding radius of the whole world (r_shape + |centroid - com|: conservative whatever the rotation;
+    //    a property of the bodies, known since the upload) and how many bodies every rank owns
     struct Head {
         double rmax;
         uint64_t count;
     };
-    std::vector<Head> head(n_local, Head{0.0, 0});
+    std::vector<Head> head(n_local);
     for (size_t k = 0; k < n_local; ++k) {
-        const Shard &s = mw->shards[k];
-        const size_t cnt = s.held_ids.size();
-        head[k].count = cnt;
-        centre[k].resize(3 * cnt);
-        for (size_t i = 0; i < cnt && st.ok(); ++i) {
-            const double *b = &s.held[i * kRigid];
-            const uint32_t sid = s.held_sid[i];
-            double off2 = 0.0;
-            for (int a = 0; a < 3; ++a) {
-                const double c = b[31 + a] + b[28 + a];
-                if (!std::isfinite(c))
-                    st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u has a non-finite position: it cannot be placed in the grid "
-                                                      "the shards are cut from", s.held_ids[i]));
-                centre[k][3 * i + a] = c;
-                const double d = mw->shape_centroid[3 * (size_t)sid + a] - b[28 + a];
-                off2 += d * d;
-            }
-            const double r = mw->shape_radius[sid] + std::sqrt(off2);
-            if (r > head[k].rmax)
-                head[k].rmax = r;
-        }
+        head[k] = Head{mw->rmax_local, mw->shards[k].held_ids.size()};
         send[k] = &head[k];
     }
     MW_TRY(all_gather_host(mw, send, sizeof(Head), gathered, st));
@@ -706,17 +749,28 @@ int make_plan(xpbd_multi_world *mw)
     if (total_held != n)
         st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: the ranks hold %llu bodies together, the world has %u", (unsigned long long)total_held, n));
 
-    // 2. grid cell of every body of the world (16 bytes per body, one all-gather): key, global id, and who holds it
+    // 2. grid cell of every body of the world (centre = position + center_of_mass; computed where the bodies are, 8 bytes per
+    //    body come back), one all-gather of 16 bytes per body: key, global id
     std::vector<std::vector<KeyRow>> key_rows(n_local);
-    for (size_t k = 0; k < n_local; ++k) {
-        const Shard &s = mw->shards[k];
-        key_rows[k].assign(max_held, KeyRow{0, UINT32_MAX, 0});
-        for (size_t i = 0; i < s.held_ids.size() && st.ok(); ++i)
-            key_rows[k][i] = KeyRow{cell_key(clamp_cell(std::floor(centre[k][3 * i] / edge)), clamp_cell(std::floor(centre[k][3 * i + 1] / edge)),
-                                             clamp_cell(std::floor(centre[k][3 * i + 2] / edge))),
-                                    s.held_ids[i], s.held_sid[i]};
-        send[k] = key_rows[k].data();
+    {
+        std::vector<int64_t> own_keys;
+        for (size_t k = 0; k < n_local; ++k) {
+            Shard &s = mw->shards[k];
+            const uint32_t cnt = (uint32_t)s.held_ids.size();
+            key_rows[k].assign(max_held, KeyRow{0, UINT32_MAX, 0});
+            own_keys.assign(cnt, 0);
+            uint32_t bad = UINT32_MAX;
+            if (st.ok())
+                st.keep(xpbd::halo_cell_keys(s.world, s.owned_slots.as<uint32_t>(), cnt, edge, own_keys.data(), &bad));
+            if (st.ok() && bad != UINT32_MAX)
+                st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u has a non-finite position: it cannot be placed in the grid the shards "
+                                                  "are cut from", s.held_ids[bad]));
+            for (uint32_t i = 0; i < cnt && st.ok(); ++i)
+                key_rows[k][i] = KeyRow{own_keys[i], s.held_ids[i], 0};
+            send[k] = key_rows[k].data();
+        }
     }
+    lap("cell keys (device)");
     MW_TRY(all_gather_host(mw, send, (size_t)max_held * sizeof(KeyRow), gathered, st));
     std::vector<int64_t> keys(n, 0);
     std::vector<uint8_t> holder(n, 0xFF);
@@ -733,8 +787,9 @@ int make_plan(xpbd_multi_world *mw)
             holder[rows[i].id] = (uint8_t)r;
         }
     }
+    lap("keys of the world");
 
-    // 3. ownership: the x-major cell sequence cut into runs of near-equal body count; then who mirrors whom
+    // 3. ownership: the cell sequence (longest axis first) cut into runs of near-equal body count; then who mirrors whom
     std::vector<uint8_t> owner(n, 0);
     std::vector<uint32_t> owned_count(w, 0);
     std::vector<std::vector<uint32_t>> own(n_local), exports(n_local);
@@ -752,6 +807,7 @@ int make_plan(xpbd_multi_world *mw)
             ++owned_count[owner[g]];
             migrated += owner[g] != holder[g];
         }
+        lap("cuts, owners");
         HaloPlanner planner;
         planner.n = n, planner.w = w, planner.keys = keys.data(), planner.owner = owner.data();
         for (size_t k = 0; k < n_local; ++k) {
@@ -764,6 +820,7 @@ int make_plan(xpbd_multi_world *mw)
         }
     }
     mw->cell_edge = edge;
+    lap("halo plans");
 
     // 4. the boundary lists of all ranks (ascending global ids) fix the rows of the per-substep all-gather; the export lists
     //    those of the plan-time record exchange
@@ -796,11 +853,10 @@ int make_plan(xpbd_multi_world *mw)
         MW_TRY(all_gather_host(mw, send, (size_t)cap * 4, gathered, st));
         std::memcpy(lists.data(), gathered.data(), lists.size() * 4);
     }
-    // the records of the exported bodies travel only when a holder may live in another process
-    const bool exchange_records = !mw->shortcut() && cap_exp > 0;
+    // the records of the exported bodies: gathered on the device that holds them, 39 doubles each
     std::vector<uint32_t> exp_lists;
     std::vector<double> exp_records;
-    if (exchange_records) {
+    if (cap_exp > 0) {
         std::vector<std::vector<uint32_t>> pad_list(n_local);
         std::vector<std::vector<double>> pad_rec(n_local);
         for (size_t k = 0; k < n_local; ++k) {
@@ -812,72 +868,70 @@ int make_plan(xpbd_multi_world *mw)
         MW_TRY(all_gather_host(mw, send, (size_t)cap_exp * 4, gathered, st));
         exp_lists.resize((size_t)w * cap_exp);
         std::memcpy(exp_lists.data(), gathered.data(), exp_lists.size() * 4);
+        std::vector<uint32_t> slots;
         for (size_t k = 0; k < n_local; ++k) {
-            const Shard &s = mw->shards[k];
+            Shard &s = mw->shards[k];
             pad_rec[k].assign((size_t)cap_exp * kRecord, 0.0);
-            for (size_t q = 0; q < exports[k].size() && st.ok(); ++q) {
-                const size_t i = std::lower_bound(s.held_ids.begin(), s.held_ids.end(), exports[k][q]) - s.held_ids.begin();
-                std::memcpy(&pad_rec[k][q * kRecord], &s.held[i * kRigid], kRigid * 8);
-                pad_rec[k][q * kRecord + kRigid] = (double)s.held_sid[i];
-            }
+            slots.clear();
+            if (st.ok())
+                for (uint32_t g : exports[k])
+                    slots.push_back(s.owned_slots_h[std::lower_bound(s.held_ids.begin(), s.held_ids.end(), g) - s.held_ids.begin()]);
+            if (st.ok())
+                st.keep(xpbd::download_records(s.world, slots.data(), (uint32_t)slots.size(), pad_rec[k].data()));
             send[k] = pad_rec[k].data();
         }
         MW_TRY(all_gather_host(mw, send, (size_t)cap_exp * kRecord * 8, gathered, st));
         exp_records.resize((size_t)w * cap_exp * kRecord);
         std::memcpy(exp_records.data(), gathered.data(), exp_records.size() * 8);
     }
+    lap("lists, exported records");
 
-    // 5. every shard's local world: owned + ghost bodies in ascending global id.  A body's record comes from the shard
-    //    itself if it holds the body, from another local shard (one process, several GPUs), or from the exchange.
+    // 5. every shard's local world: owned + ghost bodies in ascending global id.  A body the shard owned before and still
+    //    owns moves on the device; a body that arrives (a new owner, a ghost) comes from its holder's exported record.
     const uint32_t rows = mw->rows_per_rank();
-    auto record_of = [&](const Shard &me, uint32_t g, double *rec39) -> int {
-        const Shard *src = nullptr;
+    auto exported = [&](const Shard &me, uint32_t g) -> const double * {
         const uint32_t h = holder[g];
-        if (h == me.rank)
-            src = &me;
-        else if (!exchange_records)
-            src = mw->local_shard(h);
-        if (src) {
-            const auto at = std::lower_bound(src->held_ids.begin(), src->held_ids.end(), g);
-            if (at == src->held_ids.end() || *at != g)
-                return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is not among the bodies rank %u holds (inconsistent plans)", g, h);
-            const size_t i = at - src->held_ids.begin();
-            std::memcpy(rec39, &src->held[i * kRigid], kRigid * 8);
-            rec39[kRigid] = (double)src->held_sid[i];
-            return XPBD_OK;
-        }
-        if (!exchange_records)
-            return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is held by rank %u, which is not in this process", g, h);
-        const uint32_t *lo = &exp_lists[(size_t)h * cap_exp], *hi = lo + counts[h].exports;
+        const uint32_t *lo = exp_lists.data() + (size_t)h * cap_exp, *hi = lo + counts[h].exports;
         const uint32_t *at = std::lower_bound(lo, hi, g);
-        if (at == hi || *at != g)
-            return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is needed by rank %u but not exported by its holder %u (inconsistent plans)", g, me.rank, h);
-        std::memcpy(rec39, &exp_records[((size_t)h * cap_exp + (size_t)(at - lo)) * kRecord], kRecord * 8);
-        return XPBD_OK;
+        if (at == hi || *at != g) {
+            (void)set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is needed by rank %u but not exported by its holder %u (inconsistent plans)", g, me.rank, h);
+            return nullptr;
+        }
+        return &exp_records[((size_t)h * cap_exp + (size_t)(at - lo)) * kRecord];
     };
-    std::vector<std::vector<double>> new_held(n_local);
-    std::vector<std::vector<uint32_t>> new_sid(n_local);
+    if (mw->slot_of.size() != n)
+        mw->slot_of.assign(n, -1);
     auto build_shard = [&](size_t k) -> int {
         Shard &s = mw->shards[k];
         MW_TRY(bind(s));
         const uint32_t n_own = (uint32_t)own[k].size(), n_ghost = (uint32_t)s.ghosts.size(), n_loc = n_own + n_ghost;
-        std::vector<double> aos((size_t)n_loc * kRigid);
-        std::vector<uint32_t> sid(n_loc), ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(s.boundary.size()), owned_slots(n_own);
-        s.local_ids.resize(n_loc);
-        new_held[k].resize((size_t)n_own * kRigid);
-        new_sid[k].resize(n_own);
-        uint32_t slot = 0, oi = 0, gi = 0;
-        double rec[kRecord];
+        std::vector<int32_t> src(n_loc);
+        std::vector<double> incoming;
+        std::vector<uint32_t> ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(s.boundary.size()), owned_slots(n_own);
+        std::vector<uint32_t> local_ids(n_loc);
+        uint32_t slot = 0, oi = 0, gi = 0, n_in = 0;
+        size_t old = 0; // walks the bodies owned so far (ascending, like own[k])
         while (oi < n_own || gi < n_ghost) {
             const bool take_own = gi >= n_ghost || (oi < n_own && own[k][oi] < s.ghosts[gi]);
             const uint32_t g = take_own ? own[k][oi] : s.ghosts[gi];
-            MW_TRY(record_of(s, g, rec));
-            std::memcpy(&aos[(size_t)slot * kRigid], rec, kRigid * 8);
-            sid[slot] = (uint32_t)rec[kRigid];
-            s.local_ids[slot] = g;
+            local_ids[slot] = g;
+            bool here = false;
+            if (take_own && holder[g] == s.rank) {
+                while (old < s.held_ids.size() && s.held_ids[old] < g)
+                    ++old;
+                if (old == s.held_ids.size() || s.held_ids[old] != g)
+                    return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is not among the bodies rank %u holds (inconsistent plans)", g, s.rank);
+                src[slot] = (int32_t)s.owned_slots_h[old];
+                here = true;
+            }
+            if (!here) {
+                const double *rec = exported(s, g);
+                if (!rec)
+                    return XPBD_E_HIP;
+                incoming.insert(incoming.end(), rec, rec + kRecord);
+                src[slot] = -(int32_t)(++n_in);
+            }
             if (take_own) {
-                std::memcpy(&new_held[k][(size_t)oi * kRigid], rec, kRigid * 8);
-                new_sid[k][oi] = sid[slot];
                 owned_slots[oi++] = slot;
             } else {
                 const uint32_t o = owner[g];
@@ -893,22 +947,29 @@ int make_plan(xpbd_multi_world *mw)
         }
         for (size_t q = 0; q < s.boundary.size(); ++q)
             boundary_slots[q] = owned_slots[std::lower_bound(own[k].begin(), own[k].end(), s.boundary[q]) - own[k].begin()];
-        if (int rc = xpbd_world_upload_bodies(s.world, reinterpret_cast<const xpbd_rigid *>(aos.data()), sid.data(), n_loc))
+        lap("  source map of a shard");
+        if (int rc = xpbd::repack_bodies(s.world, src.data(), n_loc, incoming.data(), n_in))
             return rc;
+        lap("  re-pack on the device");
         // joints whose two bodies are both present here, in global joint order, re-indexed to local slots
+        for (uint32_t q = 0; q < n_loc; ++q)
+            mw->slot_of[local_ids[q]] = (int32_t)q;
         std::vector<xpbd_joint> local_joints;
         for (const xpbd_joint &j : mw->joints) {
-            const auto a = std::lower_bound(s.local_ids.begin(), s.local_ids.end(), j.body_a), b = std::lower_bound(s.local_ids.begin(), s.local_ids.end(), j.body_b);
-            if (a == s.local_ids.end() || *a != j.body_a || b == s.local_ids.end() || *b != j.body_b)
+            const int32_t a = mw->slot_of[j.body_a], b = mw->slot_of[j.body_b];
+            if (a < 0 || b < 0)
                 continue;
             xpbd_joint l = j;
-            l.body_a = (uint32_t)(a - s.local_ids.begin());
-            l.body_b = (uint32_t)(b - s.local_ids.begin());
+            l.body_a = (uint32_t)a;
+            l.body_b = (uint32_t)b;
             local_joints.push_back(l);
         }
+        for (uint32_t q = 0; q < n_loc; ++q)
+            mw->slot_of[local_ids[q]] = -1;
         if (int rc = xpbd_world_set_joints(s.world, local_joints.data(), (uint32_t)local_joints.size()))
             return rc;
         MW_HIP_TRY(hipStreamSynchronize(s.stream));
+        lap("  joints");
         MW_TRY(upload_vector(s.boundary_slots, boundary_slots, s.stream));
         MW_TRY(upload_vector(s.ghost_slots, ghost_slots, s.stream));
         MW_TRY(upload_vector(s.ghost_rows, ghost_rows, s.stream));
@@ -922,10 +983,9 @@ int make_plan(xpbd_multi_world *mw)
         // 1 / allowance^2 per owned body: the displacement check then yields the largest FRACTION of its allowance any body has used
         std::vector<double> scale(n_own);
         const double near_allow = mw->margin, far_allow = mw->margin + 0.5 * edge;
-        for (uint32_t i = 0; i < n_own; ++i) {
-            const double allow = s.far[i] ? far_allow : near_allow;
-            scale[i] = 1.0 / (allow * allow);
-        }
+        const double near_scale = 1.0 / (near_allow * near_allow), far_scale = 1.0 / (far_allow * far_allow);
+        for (uint32_t i = 0; i < n_own; ++i)
+            scale[i] = s.far[i] ? far_scale : near_scale;
         MW_TRY(upload_vector(s.disp_scale, scale, s.stream));
         MW_HIP_TRY(s.send.reserve((size_t)rows * kDyn * 8));
         MW_HIP_TRY(s.recv.reserve((size_t)w * rows * kDyn * 8));
@@ -937,20 +997,17 @@ int make_plan(xpbd_multi_world *mw)
             return rc;
         MW_HIP_TRY(hipStreamSynchronize(s.stream)); // the host vectors above go out of scope
         s.owned_slots_h.swap(owned_slots);
+        s.local_ids.swap(local_ids);
+        s.held_ids.swap(own[k]); // from now on the shard holds what it owns
+        lap("  index lists of a shard");
         return XPBD_OK;
     };
     for (size_t k = 0; k < n_local && st.ok(); ++k)
         st.keep(build_shard(k));
-    // all ranks leave the plan together: a last status-only exchange (a failed upload on one rank fails the plan everywhere)
+    // all ranks leave the plan together: a last status-only exchange (a failed re-pack on one rank fails the plan everywhere)
     for (size_t k = 0; k < n_local; ++k)
         send[k] = nullptr;
     MW_TRY(all_gather_host(mw, send, 0, gathered, st));
-    for (size_t k = 0; k < n_local; ++k) { // from now on the shards hold what they own
-        Shard &s = mw->shards[k];
-        s.held_ids.swap(own[k]);
-        s.held.swap(new_held[k]);
-        s.held_sid.swap(new_sid[k]);
-    }
     mw->owner.swap(owner);
     mw->owned_count.swap(owned_count);
     mw->migrated = migrated;
@@ -958,20 +1015,24 @@ int make_plan(xpbd_multi_world *mw)
     mw->violated = false;
     mw->last_displacement = 0.0;
     ++mw->plans;
+    mw->ns_plan += now_ns() - t_plan;
     return XPBD_OK;
 }
 
-// The owned bodies' current state back into Shard::held (for a re-plan or a download).
-int fetch_owned(xpbd_multi_world *mw)
+// The owned bodies' current state (ascending global id, like Shard::held_ids), for a download.
+int fetch_owned(xpbd_multi_world *mw, std::vector<std::vector<double>> &held)
 {
-    for (Shard &s : mw->shards) {
+    held.assign(mw->shards.size(), std::vector<double>());
+    for (size_t k = 0; k < mw->shards.size(); ++k) {
+        Shard &s = mw->shards[k];
         MW_TRY(bind(s));
         const uint32_t n_loc = (uint32_t)s.local_ids.size();
         std::vector<double> aos((size_t)n_loc * kRigid);
         if (int rc = xpbd_world_download_bodies(s.world, reinterpret_cast<xpbd_rigid *>(aos.data()), n_loc))
             return rc;
+        held[k].resize(s.held_ids.size() * kRigid);
         for (size_t i = 0; i < s.held_ids.size(); ++i)
-            std::memcpy(&s.held[i * kRigid], &aos[(size_t)s.owned_slots_h[i] * kRigid], kRigid * 8);
+            std::memcpy(&held[k][i * kRigid], &aos[(size_t)s.owned_slots_h[i] * kRigid], kRigid * 8);
     }
     return XPBD_OK;
 }
@@ -979,19 +1040,7 @@ int fetch_owned(xpbd_multi_world *mw)
 int replan(xpbd_multi_world *mw)
 {
     LocalStatus st;
-    st.keep(fetch_owned(mw));
-    if (!st.ok()) { // the plan's first collective tells the others
-        std::vector<const void *> send(mw->shards.size(), nullptr);
-        std::vector<uint8_t> gathered;
-        struct Head {
-            double rmax;
-            uint64_t count;
-        } dummy{0.0, 0};
-        for (auto &p : send)
-            p = &dummy;
-        return all_gather_host(mw, send, sizeof dummy, gathered, st);
-    }
-    return make_plan(mw);
+    return make_plan(mw, st);
 }
 
 // Enqueues one whole frame on every local shard and, behind it, the end-of-frame exchange: per rank the largest fraction of
@@ -1550,22 +1599,42 @@ int xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, cons
     mw->n_global = n_global, mw->first_global = first_global, mw->n_bodies = n_bodies;
     mw->joints.assign(joints, joints + n_joints);
     mw->planned = false;
+    // the largest bounding radius among the bodies handed over here (r_shape + |centroid - com|: a property of the bodies)
+    mw->rmax_local = 0.0;
+    for (uint32_t i = 0; i < n_bodies; ++i) {
+        const uint32_t sid = shape_id ? shape_id[i] : 0u;
+        double off2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double d = mw->shape_centroid[3 * (size_t)sid + a] - bodies[i].center_of_mass[a];
+            off2 += d * d;
+        }
+        mw->rmax_local = std::max(mw->rmax_local, mw->shape_radius[sid] + std::sqrt(off2));
+    }
+    // every shard's slice goes to its device as it is: a world of owned bodies only, which the first plan re-packs
+    LocalStatus st;
     for (Shard &s : mw->shards) {
         const Range slice = shard_range(n_global, s.rank, mw->n_ranks);
         s.held_ids.resize(slice.count);
-        s.held.resize((size_t)slice.count * kRigid);
-        s.held_sid.assign(slice.count, 0);
+        s.owned_slots_h.resize(slice.count);
         for (uint32_t i = 0; i < slice.count; ++i)
-            s.held_ids[i] = slice.first + i;
-        if (slice.count) {
-            std::memcpy(s.held.data(), bodies + (slice.first - first_global), (size_t)slice.count * sizeof(xpbd_rigid));
-            if (shape_id)
-                std::memcpy(s.held_sid.data(), shape_id + (slice.first - first_global), (size_t)slice.count * 4);
-        }
+            s.held_ids[i] = slice.first + i, s.owned_slots_h[i] = i;
+        s.local_ids = s.held_ids;
+        s.ghosts.clear(), s.boundary.clear();
+        auto upload = [&]() -> int {
+            MW_TRY(bind(s));
+            if (int rc = xpbd_world_upload_bodies(s.world, bodies + (slice.first - first_global), shape_id ? shape_id + (slice.first - first_global) : nullptr,
+                                                  slice.count))
+                return rc;
+            MW_TRY(upload_vector(s.owned_slots, s.owned_slots_h, s.stream));
+            MW_HIP_TRY(hipStreamSynchronize(s.stream));
+            return XPBD_OK;
+        };
+        if (st.ok())
+            st.keep(upload());
     }
     mw->plans = 0;
     mw->rollbacks = 0;
-    return make_plan(mw);
+    return make_plan(mw, st);
 }
 
 int xpbd_multi_world_replan(xpbd_multi_world *mw)
@@ -1604,10 +1673,12 @@ int xpbd_multi_world_step(xpbd_multi_world *mw, double dt, uint32_t substeps)
             (void)restore_frame(mw); // best effort: the state of the frame's start, on every rank
             return set_error(rc, "%s", msg.c_str());
         }
+        const double gain = std::max(0.0, moved - mw->last_displacement); // what this frame used up of the allowance
         mw->last_displacement = moved;
         if (moved <= mw->margin) {
-            // pre-emptive: half the allowance is gone, so re-plan (and re-balance) from the state just reached
-            if ((mw->flags & XPBD_MULTI_AUTO_REPLAN) && moved > 0.5 * mw->margin)
+            // pre-emptive: another frame like this one (and half as much again) would outrun the allowance, so re-plan (and
+            // re-balance) from the state just reached.  A wrong guess costs a frame: it is undone and run again below.
+            if ((mw->flags & XPBD_MULTI_AUTO_REPLAN) && moved + 1.5 * gain > mw->margin)
                 MW_TRY(replan(mw));
             return XPBD_OK;
         }
@@ -1649,13 +1720,15 @@ int xpbd_multi_world_download_owned(xpbd_multi_world *mw, uint32_t *ids, xpbd_ri
     *n_out = (uint32_t)total;
     if (total > cap)
         return set_error(XPBD_E_CAPACITY, "xpbd_multi_world_download_owned: %zu owned bodies, capacity %u", total, cap);
-    MW_TRY(fetch_owned(mw));
+    std::vector<std::vector<double>> held;
+    MW_TRY(fetch_owned(mw, held));
     size_t at = 0;
-    for (const Shard &s : mw->shards) {
+    for (size_t k = 0; k < mw->shards.size(); ++k) {
+        const Shard &s = mw->shards[k];
         if (s.held_ids.empty())
             continue;
         std::memcpy(ids + at, s.held_ids.data(), s.held_ids.size() * 4);
-        std::memcpy(out + at, s.held.data(), s.held_ids.size() * sizeof(xpbd_rigid));
+        std::memcpy(out + at, held[k].data(), s.held_ids.size() * sizeof(xpbd_rigid));
         at += s.held_ids.size();
     }
     return XPBD_OK;
@@ -1669,14 +1742,17 @@ int xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n)
     if (!mw->planned || n != mw->n_bodies)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_download: n = %u but this process handed over %u bodies", n, mw->planned ? mw->n_bodies : 0);
     LocalStatus st;
-    st.keep(fetch_owned(mw));
+    std::vector<std::vector<double>> held;
+    st.keep(fetch_owned(mw, held));
     const uint32_t lo = mw->first_global, hi = mw->first_global + mw->n_bodies;
     if (mw->shortcut()) { // every owner is here
         if (!st.ok())
             return st.report();
-        for (const Shard &s : mw->shards)
+        for (size_t k = 0; k < mw->shards.size(); ++k) {
+            const Shard &s = mw->shards[k];
             for (size_t i = 0; i < s.held_ids.size(); ++i)
-                std::memcpy(out + (s.held_ids[i] - lo), &s.held[i * kRigid], sizeof(xpbd_rigid));
+                std::memcpy(out + (s.held_ids[i] - lo), &held[k][i * kRigid], sizeof(xpbd_rigid));
+        }
         return XPBD_OK;
     }
     // one all-gather of every rank's owned bodies (id + state); each process keeps the slice it handed over
@@ -1689,9 +1765,9 @@ int xpbd_multi_world_download(xpbd_multi_world *mw, xpbd_rigid *out, uint32_t n)
     for (size_t k = 0; k < n_local; ++k) {
         const Shard &s = mw->shards[k];
         payload[k].assign((size_t)cap * row, 0xFF);
-        for (size_t i = 0; i < s.held_ids.size(); ++i) {
+        for (size_t i = 0; i < s.held_ids.size() && st.ok(); ++i) {
             std::memcpy(&payload[k][i * row], &s.held_ids[i], 4);
-            std::memcpy(&payload[k][i * row + 4], &s.held[i * kRigid], kRigid * 8);
+            std::memcpy(&payload[k][i * row + 4], &held[k][i * kRigid], kRigid * 8);
         }
         send[k] = payload[k].data();
     }
@@ -1739,7 +1815,7 @@ int xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10])
         hi = std::max(hi, c);
     }
     out[0] = mw->plans, out[1] = mw->rollbacks, out[2] = mw->migrated, out[3] = mw->owned_count.empty() ? 0 : lo, out[4] = hi;
-    out[5] = mw->steps, out[6] = mw->ns_enqueue, out[7] = mw->ns_wait_broadphase, out[8] = mw->ns_wait_frame, out[9] = 0;
+    out[5] = mw->steps, out[6] = mw->ns_enqueue, out[7] = mw->ns_wait_broadphase, out[8] = mw->ns_wait_frame, out[9] = mw->ns_plan;
     return XPBD_OK;
 }
 

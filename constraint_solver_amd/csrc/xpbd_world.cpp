@@ -153,6 +153,9 @@ struct xpbd_world {
     // 128-byte record per body and per neighbour.  Same values, so the same bits.
     bool stat_shared = false;
     std::vector<double> stat_shape_host; // [n_shapes][kStatRecDoubles]
+    std::vector<uint8_t> stat_shape_seen; // [n_shapes] a body of the shape has been uploaded: its row of stat_shape_host is set
+    // re-packing the bodies on the device (xpbd::repack_bodies): the new world in AoS, its shape ids, the source map, incoming records
+    DeviceBuffer repack_aos, repack_shape, repack_src, repack_incoming, halo_keys, halo_records;
     DeviceBuffer cb_stat_shape;
     DeviceBuffer cb_grid_partials, cb_items_unsorted;
     uint32_t table_size = 0, n_entries = 0, n_pairs = 0;
@@ -607,6 +610,144 @@ int halo_substep_ghosts(xpbd_world *w, double h, uint32_t k, bool last, const Ha
 
 } // namespace xpbd
 
+namespace {
+// Do all bodies of a shape share their mass properties bit for bit?  (see stat_shared)  One more body of shape `sid`.
+void absorb_stat_record(xpbd_world *w, const xpbd_rigid &body, uint32_t sid)
+{
+    double v[xpbd::kStatRecDoubles] = {};
+    v[0] = body.inverse_mass;
+    std::memcpy(v + 1, body.inverse_inertia, 9 * sizeof(double));
+    std::memcpy(v + 10, body.center_of_mass, 3 * sizeof(double));
+    double *slot = w->stat_shape_host.data() + (size_t)sid * xpbd::kStatRecDoubles;
+    if (!w->stat_shape_seen[sid]) {
+        std::memcpy(slot, v, sizeof v);
+        w->stat_shape_seen[sid] = 1;
+    } else if (std::memcmp(slot, v, sizeof v) != 0) {
+        w->stat_shared = false;
+    }
+}
+} // namespace
+
+// ---- re-planning a shard of the multi-GPU world on the device (xpbd_multi.cpp) ---------------------------------------------
+namespace xpbd {
+
+int halo_cell_keys(xpbd_world *w, const uint32_t *dev_slots, uint32_t n, double edge, int64_t *host_keys, uint32_t *bad_index)
+{
+    *bad_index = UINT32_MAX;
+    if (n == 0)
+        return XPBD_OK;
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream)); // reserve() may free a block
+    XPBD_HIP_TRY(w->halo_keys.reserve((size_t)n * 8 + 8));
+    uint32_t *bad = reinterpret_cast<uint32_t *>(w->halo_keys.as<int64_t>() + n);
+    XPBD_HIP_TRY(hipMemsetAsync(bad, 0xFF, 4, w->stream));
+    XPBD_HIP_TRY(launch_cell_keys(w->arrays(), dev_slots, n, edge, w->halo_keys.as<int64_t>(), bad, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(host_keys, w->halo_keys.ptr, (size_t)n * 8, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(bad_index, bad, 4, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
+int download_records(xpbd_world *w, const uint32_t *host_slots, uint32_t n, double *out39)
+{
+    if (n == 0)
+        return XPBD_OK;
+    for (uint32_t k = 0; k < n; ++k)
+        if (host_slots[k] >= w->n)
+            return fail(XPBD_E_INVALID, "xpbd::download_records: slot %u of a world of %u bodies", host_slots[k], w->n);
+    if (int rc = bind_device(w))
+        return rc;
+    constexpr size_t rec = (size_t)(kRigidDoubles + 1) * 8;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    XPBD_HIP_TRY(w->halo_records.reserve((size_t)n * rec));
+    XPBD_HIP_TRY(w->repack_src.reserve((size_t)n * 4));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->repack_src.ptr, host_slots, (size_t)n * 4, hipMemcpyHostToDevice, w->stream));
+    XPBD_HIP_TRY(launch_gather_records(w->arrays(), w->repack_src.as<uint32_t>(), n, w->halo_records.as<double>(), w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(out39, w->halo_records.ptr, (size_t)n * rec, hipMemcpyDeviceToHost, w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    return XPBD_OK;
+}
+
+// The world's bodies become: body s = the present body src[s] (src[s] >= 0) or incoming record -src[s] - 1 (39 doubles: an
+// xpbd_rigid and its shape id).  Everything stays on the device but the incoming records; otherwise as xpbd_world_upload_bodies
+// (joints, history, contact masks and the neighbour lists are dropped).
+int repack_bodies(xpbd_world *w, const int32_t *host_src, uint32_t n_new, const double *incoming39, uint32_t n_incoming)
+{
+    if (!w || (n_new && !host_src) || (n_incoming && !incoming39))
+        return fail(XPBD_E_INVALID, "xpbd::repack_bodies: NULL argument");
+    constexpr uint32_t rec = kRigidDoubles + 1;
+    uint32_t max_shape_id = w->max_shape_id;
+    for (uint32_t s = 0; s < n_new; ++s) {
+        const int32_t from = host_src[s];
+        if (from >= 0 ? (uint32_t)from >= w->n : (uint32_t)(-(from + 1)) >= n_incoming)
+            return fail(XPBD_E_INVALID, "xpbd::repack_bodies: body %u comes from %d (%u bodies present, %u incoming)", s, from, w->n, n_incoming);
+    }
+    for (uint32_t k = 0; k < n_incoming; ++k) {
+        const double sid = incoming39[(size_t)k * rec + kRigidDoubles];
+        if (!(sid >= 0.0) || sid >= (double)w->n_shapes)
+            return fail(XPBD_E_INVALID, "xpbd::repack_bodies: incoming record %u has shape id %g of %u", k, sid, w->n_shapes);
+        max_shape_id = std::max(max_shape_id, (uint32_t)sid);
+    }
+    if (int rc = bind_device(w))
+        return rc;
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream));
+    // 1. the present bodies in AoS, the new ones gathered from them and from the incoming records
+    XPBD_HIP_TRY(w->aos_staging.reserve((size_t)std::max(w->n, 1u) * sizeof(xpbd_rigid)));
+    XPBD_HIP_TRY(w->repack_aos.reserve((size_t)std::max(n_new, 1u) * sizeof(xpbd_rigid)));
+    XPBD_HIP_TRY(w->repack_shape.reserve((size_t)std::max(n_new, 1u) * 4));
+    XPBD_HIP_TRY(w->repack_src.reserve((size_t)std::max(n_new, 1u) * 4));
+    XPBD_HIP_TRY(w->repack_incoming.reserve((size_t)std::max(n_incoming, 1u) * rec * 8));
+    XPBD_HIP_TRY(launch_soa_to_aos(w->arrays(), w->aos_staging.as<double>(), w->stream));
+    if (n_new)
+        XPBD_HIP_TRY(hipMemcpyAsync(w->repack_src.ptr, host_src, (size_t)n_new * 4, hipMemcpyHostToDevice, w->stream));
+    if (n_incoming)
+        XPBD_HIP_TRY(hipMemcpyAsync(w->repack_incoming.ptr, incoming39, (size_t)n_incoming * rec * 8, hipMemcpyHostToDevice, w->stream));
+    XPBD_HIP_TRY(launch_repack_bodies(w->aos_staging.as<double>(), w->shape_id.as<uint32_t>(), w->repack_src.as<int32_t>(), n_new,
+                                      w->repack_incoming.as<double>(), w->repack_aos.as<double>(), w->repack_shape.as<uint32_t>(), w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream)); // the arrays below may move
+    // 2. the world takes the new size (as xpbd_world_upload_bodies)
+    const uint32_t stride = round_up(n_new ? n_new : 1, 256);
+    XPBD_HIP_TRY(w->dyn.reserve((size_t)kDynFields * stride * 8));
+    XPBD_HIP_TRY(w->stat.reserve((size_t)kStatFields * stride * 8));
+    XPBD_HIP_TRY(w->shape_id.reserve((size_t)stride * 4));
+    XPBD_HIP_TRY(w->last_mask.reserve((size_t)stride * 4));
+    XPBD_HIP_TRY(w->aos_staging.reserve((size_t)(n_new ? n_new : 1) * sizeof(xpbd_rigid)));
+    w->have_neighbours = false;
+    w->n_joints = 0;
+    w->history_length = 0;
+    w->history_stepped.clear();
+    w->n = n_new;
+    w->stride = stride;
+    w->stat_rec_valid = false;
+    w->max_shape_id = max_shape_id;
+    w->stepped = false;
+    w->trace_rows = 0;
+    w->frame_snapshot_valid = false;
+    w->bp_pending = false;
+    // mass properties shared per shape: the bodies that stay kept the property, the incoming ones are checked
+    if (w->stat_shape_seen.size() != w->n_shapes) {
+        w->stat_shape_host.assign((size_t)w->n_shapes * kStatRecDoubles, 0.0);
+        w->stat_shape_seen.assign(w->n_shapes, 0);
+        w->stat_shared = false;
+    }
+    for (uint32_t k = 0; k < n_incoming && w->stat_shared; ++k) {
+        xpbd_rigid body;
+        std::memcpy(&body, incoming39 + (size_t)k * rec, sizeof body);
+        absorb_stat_record(w, body, (uint32_t)incoming39[(size_t)k * rec + kRigidDoubles]);
+    }
+    if (n_new == 0)
+        return XPBD_OK;
+    XPBD_HIP_TRY(hipMemsetAsync(w->shape_id.ptr, 0, (size_t)stride * 4, w->stream));
+    XPBD_HIP_TRY(hipMemcpyAsync(w->shape_id.ptr, w->repack_shape.ptr, (size_t)n_new * 4, hipMemcpyDeviceToDevice, w->stream));
+    XPBD_HIP_TRY(hipMemsetAsync(w->last_mask.ptr, 0, (size_t)stride * 4, w->stream));
+    XPBD_HIP_TRY(launch_aos_to_soa(w->repack_aos.as<double>(), w->arrays(), w->stream));
+    XPBD_HIP_TRY(hipStreamSynchronize(w->stream)); // the caller's buffers are only borrowed
+    return XPBD_OK;
+}
+
+} // namespace xpbd
+
 extern "C" {
 
 uint32_t xpbd_abi_version(void) { return XPBD_ABI_VERSION; }
@@ -702,7 +843,8 @@ void xpbd_world_destroy(xpbd_world *w)
                             &w->sat_counters, &w->sat_survivors, &w->sat_axis_cache, &w->gjk_axis_cache, &w->cb_stat_shape, &w->cb_pair_codes, &w->cb_rec_b,
                             &w->cb_grid_partials, &w->cb_items_unsorted})
         b->release();
-    w->frame_snapshot.release();
+    for (DeviceBuffer *b : {&w->frame_snapshot, &w->repack_aos, &w->repack_shape, &w->repack_src, &w->repack_incoming, &w->halo_keys, &w->halo_records})
+        b->release();
     if (w->bp_totals)
         (void)hipHostFree(w->bp_totals);
     if (w->bp_event)
@@ -964,27 +1106,11 @@ int xpbd_world_upload_bodies(xpbd_world *w, const xpbd_rigid *aos, const uint32_
     w->stride = stride;
     w->stat_rec_valid = false;
     w->max_shape_id = max_shape_id;
-    {
-        // do all bodies of a shape share their mass properties bit for bit?  (see stat_shared)
-        const size_t rec = xpbd::kStatRecDoubles;
-        w->stat_shape_host.assign((size_t)w->n_shapes * rec, 0.0);
-        std::vector<uint8_t> seen(w->n_shapes, 0);
-        w->stat_shared = n != 0;
-        for (uint32_t i = 0; i < n && w->stat_shared; ++i) {
-            const uint32_t sid = shape_id ? shape_id[i] : 0u;
-            double v[xpbd::kStatRecDoubles] = {};
-            v[0] = aos[i].inverse_mass;
-            std::memcpy(v + 1, aos[i].inverse_inertia, 9 * sizeof(double));
-            std::memcpy(v + 10, aos[i].center_of_mass, 3 * sizeof(double));
-            double *slot = w->stat_shape_host.data() + (size_t)sid * rec;
-            if (!seen[sid]) {
-                std::memcpy(slot, v, sizeof v);
-                seen[sid] = 1;
-            } else if (std::memcmp(slot, v, sizeof v) != 0) {
-                w->stat_shared = false;
-            }
-        }
-    }
+    w->stat_shape_host.assign((size_t)w->n_shapes * xpbd::kStatRecDoubles, 0.0);
+    w->stat_shape_seen.assign(w->n_shapes, 0);
+    w->stat_shared = n != 0;
+    for (uint32_t i = 0; i < n && w->stat_shared; ++i)
+        absorb_stat_record(w, aos[i], shape_id ? shape_id[i] : 0u);
     w->stepped = false;
     w->trace_rows = 0;
     w->frame_snapshot_valid = false;

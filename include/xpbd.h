@@ -335,7 +335,7 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
  * over all ranks, how much of its travel allowance any body has used since the plan (halo_margin next to a shard boundary,
  * halo_margin + half a cell edge for a body more than two cells away from every foreign one).  Beyond it a remote contact
  * may have been missed in that frame, so the frame is UNDONE (the state it started from is kept aside on the device) and
- * either run again after a re-plan (XPBD_MULTI_AUTO_REPLAN, which also re-plans pre-emptively at half the allowance) or
+ * either run again after a re-plan (XPBD_MULTI_AUTO_REPLAN, which also re-plans pre-emptively when another frame like the last one would outrun the allowance) or
  * reported as XPBD_E_HALO with the frame's start state in place.  Result: bit-identical to one xpbd_world over the same bodies
  * in the same order -- a state with possibly missed contacts never reaches the caller.
  *
@@ -416,7 +416,7 @@ int  xpbd_multi_world_download_owned(xpbd_multi_world *mw, uint32_t *ids, xpbd_r
 int  xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *max_displacement);
 /* out = {plans made, frames undone (halo violations), bodies that changed owner at the last plan, fewest / most bodies owned
  * by a rank, step calls, and the host time inside them in ns: enqueueing, waiting for the broadphases' pair counts, waiting
- * for the end of the frame; 0}. */
+ * for the end of the frame; the host time of all plans (creation and re-plans) in ns}. */
 int  xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10]);
 /* owner[g] = rank that owns body g as of the last plan (n_global entries). */
 int  xpbd_multi_world_owners(xpbd_multi_world *mw, uint8_t *owner, uint32_t n_global);

@@ -150,15 +150,15 @@ def test_a_frame_in_which_a_body_outruns_the_halo_margin_is_undone_and_reported(
 
 
 def test_automatic_replanning_undoes_and_reruns_a_frame_that_outran_its_halos():
-    """A body that accelerates: 0.2 m in the first frame (no pre-emptive re-plan yet: that comes at half the margin), 0.4 m
-    more in the second -- 0.6 m since the plan, beyond the 0.5 m margin.  With XPBD_MULTI_AUTO_REPLAN the second frame is
-    undone, the halos are re-planned from its start state and the frame runs again: the caller sees nothing but the
-    single-device result."""
+    """A body that accelerates from rest: 0.19 m in the first frame (no pre-emptive re-plan: two and a half times that
+    still fits the 0.5 m margin), 0.49 m more in the second -- 0.68 m since the plan.  With XPBD_MULTI_AUTO_REPLAN the second
+    frame is undone, the halos are re-planned from its start state and the frame runs again: the caller sees nothing but
+    the single-device result."""
     kind, n, substeps, margin = capi.SCENE_BOXES_DROP, 64, 4, 0.5
     bodies, sid = line_scene(capi, kind, n, 3, 1.5)
     fast = boundary_body(kind, bodies, sid, 2, margin)
-    bodies[fast, 22:25] = [0.0, 0.0, 6.0]
-    bodies[fast, 10:13] = [0.0, 0.0, 720.0 / bodies[fast, 0]]           # 720 m/s^2 upwards: +12 m/s per frame
+    bodies[fast, 22:25] = 0.0
+    bodies[fast, 10:13] = [0.0, 0.0, 1080.0 / bodies[fast, 0]]          # 1080 m/s^2 upwards: +18 m/s per frame
     with capi.MultiWorld(2, devices=[0, 0], transport=capi.TRANSPORT_LOCAL, halo_margin=margin, auto_replan=True) as mw:
         mw.set_polytopes(capi.scene_polytopes(kind))
         mw.upload(bodies, sid, 0, n)
