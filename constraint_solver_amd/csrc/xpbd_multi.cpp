@@ -139,28 +139,64 @@ struct Cut {
     bool operator<=(const Cut &o) const { return key < o.key || (key == o.key && id <= o.id); }
 };
 
-void multiselect(int64_t *a, size_t lo, size_t hi, const size_t *pos, size_t n_pos)
+// The planner's passes over ALL bodies of the world (every rank makes them at every re-plan) in a few host threads.
+// fn(thread, begin, end) for contiguous chunks in thread order; small inputs stay on the calling thread.
+constexpr unsigned kPlanThreads = 8;
+
+unsigned plan_threads(size_t n)
 {
-    if (n_pos == 0 || lo >= hi)
+    static const unsigned hw = [] { // XPBD_PLAN_THREADS=<1..8> overrides (1: everything on the calling thread)
+        const char *e = std::getenv("XPBD_PLAN_THREADS");
+        const unsigned want = e ? (unsigned)std::atoi(e) : std::thread::hardware_concurrency();
+        return std::max(1u, std::min(kPlanThreads, want));
+    }();
+    return n < ((size_t)1 << 16) ? 1u : hw;
+}
+
+template <class F>
+void parallel_chunks(size_t n, F fn)
+{
+    const unsigned t_count = plan_threads(n);
+    if (t_count == 1) {
+        fn(0u, (size_t)0, n);
         return;
-    const size_t mid = n_pos / 2;
-    std::nth_element(a + lo, a + pos[mid], a + hi);
-    multiselect(a, lo, pos[mid], pos, mid);
-    multiselect(a, pos[mid] + 1, hi, pos + mid + 1, n_pos - mid - 1);
+    }
+    std::vector<std::thread> threads;
+    threads.reserve(t_count - 1);
+    for (unsigned t = 1; t < t_count; ++t)
+        threads.emplace_back([&fn, t, t_count, n] { fn(t, n * t / t_count, n * (t + 1) / t_count); });
+    fn(0u, (size_t)0, n / t_count);
+    for (std::thread &th : threads)
+        th.join();
 }
 
 // The slabs are cut ACROSS THE LONGEST AXIS of the world's box of cells (a world 64 cells by 256 gets four slabs of 64 x 64,
 // not of 16 x 256: a quarter of the boundary): `order` = the axes by falling extent (ties: x, y, z), and the bodies are
-// sequenced by their cell key re-packed with the axes in that order.
-void slab_axes(const int64_t *keys, uint32_t n, int order[3])
+// sequenced by their cell key re-packed with the axes in that order.  lo / hi: the box.
+void slab_axes(const int64_t *keys, uint32_t n, int order[3], int64_t lo[3], int64_t hi[3])
 {
-    int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
-    for (uint32_t g = 0; g < n; ++g) {
-        int64_t c[3];
-        cell_of_key(keys[g], c);
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], c[a]);
-            hi[a] = std::max(hi[a], c[a]);
+    int64_t tlo[kPlanThreads][3], thi[kPlanThreads][3];
+    for (unsigned t = 0; t < kPlanThreads; ++t)
+        for (int a = 0; a < 3; ++a)
+            tlo[t][a] = INT64_MAX, thi[t][a] = INT64_MIN;
+    parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+        int64_t l[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, h[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+        for (size_t g = begin; g < end; ++g) {
+            int64_t c[3];
+            cell_of_key(keys[g], c);
+            for (int a = 0; a < 3; ++a) {
+                l[a] = std::min(l[a], c[a]);
+                h[a] = std::max(h[a], c[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a)
+            tlo[t][a] = l[a], thi[t][a] = h[a];
+    });
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = INT64_MAX, hi[a] = INT64_MIN;
+        for (unsigned t = 0; t < kPlanThreads; ++t) {
+            lo[a] = std::min(lo[a], tlo[t][a]);
+            hi[a] = std::max(hi[a], thi[t][a]);
         }
     }
     order[0] = 0, order[1] = 1, order[2] = 2;
@@ -176,63 +212,109 @@ int64_t slab_key(int64_t key, const int order[3])
     return cell_key(c[order[0]], c[order[1]], c[order[2]]);
 }
 
-// cuts[r] for r = 1 .. w - 1 (cuts[0] = the smallest possible pair) over the SLAB keys; a deterministic function of the keys alone
-void partition_cuts(const int64_t *keys, uint32_t n, uint32_t w, std::vector<Cut> &cuts)
+// Ownership of all bodies from their cell keys: owner[g], and the cuts (cuts[r] for r = 1 .. w - 1 over the SLAB keys,
+// cuts[0] = the smallest possible pair); a deterministic function of the keys alone.
+//   The body sequence (slab key, id) is cut at positions t_r = the start of rank r's equal share.  K_r = the slab key at
+// position t_r of the sorted sequence is found without sorting it: a histogram of the bodies per LAYER (the slab key's
+// leading coordinate, the one the slabs are cut across) locates the layer position t_r falls in, and only that layer's
+// bodies are gathered and sorted (a 1024-layer world: a thousandth of the bodies per cut).
+void compute_owners(const int64_t *keys, uint32_t n, uint32_t w, uint8_t *owner, std::vector<Cut> &cuts)
 {
     cuts.assign(w, Cut{INT64_MIN, 0});
-    if (n == 0 || w < 2)
+    if (n == 0)
         return;
-    std::vector<size_t> pos;
-    for (uint32_t r = 1; r < w; ++r) {
-        const size_t t = shard_range(n, r, w).first;
-        if (t < n && (pos.empty() || pos.back() != t))
-            pos.push_back(t);
-    }
-    std::vector<int64_t> a(keys, keys + n);
-    multiselect(a.data(), 0, n, pos.data(), pos.size());
-    const uint32_t share = std::max(1u, n / w);
-    for (uint32_t r = 1; r < w; ++r) {
-        const size_t t = shard_range(n, r, w).first; // bodies the ranks before r should own
-        if (t >= n) {
-            cuts[r] = Cut{INT64_MAX, UINT32_MAX};
-            continue;
+    int axes[3];
+    int64_t lo[3], hi[3];
+    slab_axes(keys, n, axes, lo, hi);
+    std::vector<int64_t> slab(n);
+    const int64_t layer_lo = lo[axes[0]];
+    const size_t n_layers = (size_t)(hi[axes[0]] - layer_lo + 1);
+    auto layer_of = [layer_lo](int64_t slab_key_) { return (size_t)(((slab_key_ >> 42) - kCellBias) - layer_lo); };
+    const unsigned t_count = plan_threads(n);
+    std::vector<std::vector<uint32_t>> hist(t_count, std::vector<uint32_t>(n_layers, 0));
+    parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+        uint32_t *h = hist[t].data();
+        for (size_t g = begin; g < end; ++g) {
+            slab[g] = slab_key(keys[g], axes);
+            ++h[layer_of(slab[g])];
         }
-        const int64_t K = a[t];
-        size_t less = 0, leq = 0;
-        for (uint32_t g = 0; g < n; ++g) {
-            less += keys[g] < K;
-            leq += keys[g] <= K;
+    });
+    if (w >= 2) {
+        std::vector<uint64_t> first(n_layers + 1, 0); // bodies in the layers before layer x
+        for (size_t x = 0; x < n_layers; ++x) {
+            uint64_t c = 0;
+            for (unsigned t = 0; t < t_count; ++t)
+                c += hist[t][x];
+            first[x + 1] = first[x] + c;
         }
-        const size_t before = t - less, after = leq - t; // bodies of cell K on the wrong side if the cut goes before / after it
-        if (std::min(before, after) * 4 <= share) {
-            cuts[r] = before <= after ? Cut{K, 0} : Cut{K + 1, 0};
-        } else { // split cell K: its `before` lowest ids stay with the ranks before r
-            std::vector<uint32_t> ids;
-            ids.reserve(leq - less);
-            for (uint32_t g = 0; g < n; ++g)
-                if (keys[g] == K)
-                    ids.push_back(g);
-            cuts[r] = Cut{K, ids[before]}; // (ascending already: g runs upwards)
+        // the layer every cut position falls in; the bodies of those layers
+        std::vector<size_t> cut_layer(w, SIZE_MAX);
+        std::vector<int32_t> slot_of_layer(n_layers, -1);
+        std::vector<std::vector<Cut>> members;
+        for (uint32_t r = 1; r < w; ++r) {
+            const size_t t = shard_range(n, r, w).first;
+            if (t >= n)
+                continue;
+            const size_t x = (size_t)(std::upper_bound(first.begin(), first.end(), (uint64_t)t) - first.begin()) - 1;
+            cut_layer[r] = x;
+            if (slot_of_layer[x] < 0) {
+                slot_of_layer[x] = (int32_t)members.size();
+                members.emplace_back();
+            }
         }
+        std::vector<std::vector<std::vector<Cut>>> found(t_count, std::vector<std::vector<Cut>>(members.size()));
+        parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+            for (size_t g = begin; g < end; ++g) {
+                const int32_t m = slot_of_layer[layer_of(slab[g])];
+                if (m >= 0)
+                    found[t][(size_t)m].push_back(Cut{slab[g], (uint32_t)g});
+            }
+        });
+        for (size_t m = 0; m < members.size(); ++m) {
+            for (unsigned t = 0; t < t_count; ++t)
+                members[m].insert(members[m].end(), found[t][m].begin(), found[t][m].end());
+            std::sort(members[m].begin(), members[m].end(), [](const Cut &a, const Cut &b) { return a.key < b.key || (a.key == b.key && a.id < b.id); });
+        }
+        const uint32_t share = std::max(1u, n / w);
+        for (uint32_t r = 1; r < w; ++r) {
+            const size_t t = shard_range(n, r, w).first; // bodies the ranks before r should own
+            if (t >= n) {
+                cuts[r] = Cut{INT64_MAX, UINT32_MAX};
+                continue;
+            }
+            const std::vector<Cut> &layer = members[(size_t)slot_of_layer[cut_layer[r]]];
+            const size_t base = (size_t)first[cut_layer[r]];
+            const int64_t K = layer[t - base].key;
+            const auto key_less = [](const Cut &c, int64_t k) { return c.key < k; };
+            const size_t i_less = (size_t)(std::lower_bound(layer.begin(), layer.end(), K, key_less) - layer.begin());
+            const size_t i_leq = (size_t)(std::lower_bound(layer.begin(), layer.end(), K + 1, key_less) - layer.begin());
+            const size_t less = base + i_less, leq = base + i_leq;
+            const size_t before = t - less, after = leq - t; // bodies of cell K on the wrong side if the cut goes before / after it
+            if (std::min(before, after) * 4 <= share)
+                cuts[r] = before <= after ? Cut{K, 0} : Cut{K + 1, 0};
+            else // split cell K: its `before` lowest ids stay with the ranks before r
+                cuts[r] = Cut{K, layer[i_less + before].id};
+        }
+        for (uint32_t r = 1; r < w; ++r) // monotone whatever the snapping did
+            if (!(cuts[r - 1] <= cuts[r]))
+                cuts[r] = cuts[r - 1];
     }
-    for (uint32_t r = 1; r < w; ++r) // monotone whatever the snapping did
-        if (!(cuts[r - 1] <= cuts[r]))
-            cuts[r] = cuts[r - 1];
-}
-
-uint32_t owner_of(const std::vector<Cut> &cuts, int64_t key, uint32_t id)
-{
-    // number of cuts <= (key, id), minus one; cuts[0] is the smallest pair
-    uint32_t lo = 0, hi = (uint32_t)cuts.size(); // cuts[lo] <= pair < cuts[hi]
-    const Cut me{key, id};
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) / 2;
-        if (cuts[mid] <= me)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    return lo;
+    const std::vector<Cut> &cuts_ref = cuts;
+    parallel_chunks(n, [&](unsigned, size_t begin, size_t end) {
+        for (size_t g = begin; g < end; ++g) {
+            // number of cuts <= (key, id), minus one; cuts[0] is the smallest pair
+            uint32_t l = 0, h = (uint32_t)cuts_ref.size(); // cuts[l] <= pair < cuts[h]
+            const Cut me{slab[g], (uint32_t)g};
+            while (h - l > 1) {
+                const uint32_t mid = (l + h) / 2;
+                if (cuts_ref[mid] <= me)
+                    l = mid;
+                else
+                    h = mid;
+            }
+            owner[g] = (uint8_t)l;
+        }
+    });
 }
 
 // Which remote bodies a rank mirrors and which of its own bodies the others mirror; a pure function of the global cell
@@ -256,19 +338,47 @@ struct HaloPlanner {
                    std::vector<uint32_t> &boundary, std::vector<uint8_t> *far = nullptr) const
     {
         own.clear();
-        // this rank's bodies and the bounding box of their cells
+        static const bool trace = std::getenv("XPBD_MULTI_TRACE_PLAN") != nullptr;
+        auto t_lap = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (trace) {
+                const auto t = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[xpbd plan_rank %u] %-24s %8.3f ms\n", rank, what, std::chrono::duration<double, std::milli>(t - t_lap).count());
+                t_lap = t;
+            }
+        };
+        // this rank's bodies and the bounding box of their cells (a pass over all bodies: in a few threads, see parallel_chunks)
         int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
-        for (uint32_t g = 0; g < n; ++g)
-            if (owner[g] == rank) {
-                own.push_back(g);
-                int64_t c[3];
-                cell_of_key(keys[g], c);
+        {
+            const unsigned t_count = plan_threads(n);
+            std::vector<std::vector<uint32_t>> part(t_count);
+            std::vector<int64_t> box((size_t)t_count * 6);
+            parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+                int64_t l[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, h[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+                std::vector<uint32_t> &mine = part[t];
+                for (size_t g = begin; g < end; ++g)
+                    if (owner[g] == rank) {
+                        mine.push_back((uint32_t)g);
+                        int64_t c[3];
+                        cell_of_key(keys[g], c);
+                        for (int a = 0; a < 3; ++a) {
+                            l[a] = std::min(l[a], c[a]);
+                            h[a] = std::max(h[a], c[a]);
+                        }
+                    }
+                for (int a = 0; a < 3; ++a)
+                    box[(size_t)t * 6 + a] = l[a], box[(size_t)t * 6 + 3 + a] = h[a];
+            });
+            for (unsigned t = 0; t < t_count; ++t) {
+                own.insert(own.end(), part[t].begin(), part[t].end());
                 for (int a = 0; a < 3; ++a) {
-                    lo[a] = std::min(lo[a], c[a]);
-                    hi[a] = std::max(hi[a], c[a]);
+                    lo[a] = std::min(lo[a], box[(size_t)t * 6 + a]);
+                    hi[a] = std::max(hi[a], box[(size_t)t * 6 + 3 + a]);
                 }
             }
+        }
         const uint32_t n_own = (uint32_t)own.size();
+        lap("own bodies, box");
         // the foreign bodies within two cells of that box: their cells, and (within one cell of the box) the possible ghosts.
         // `layers[a]`: per coordinate of the box along axis a, is there a foreign cell?  Along the axis the slabs are cut across
         // only the ends of the box have any, and own bodies more than two layers from such a coordinate -- nearly all of a
@@ -281,24 +391,40 @@ struct HaloPlanner {
         }
         std::unordered_set<int64_t> foreign_cells;
         std::vector<uint32_t> candidates;
-        for (uint32_t g = 0; g < n && n_own; ++g) {
-            if (owner[g] == rank)
-                continue;
-            int64_t c[3];
-            cell_of_key(keys[g], c);
-            bool in2 = true, in1 = true;
-            for (int a = 0; a < 3; ++a) {
-                in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
-                in1 = in1 && c[a] >= lo[a] - 1 && c[a] <= hi[a] + 1;
-            }
-            if (!in2)
-                continue;
-            foreign_cells.insert(keys[g]);
-            for (int a = 0; a < 3; ++a)
-                layers[a][(size_t)(c[a] - layer0[a])] = 1;
-            if (in1)
-                candidates.push_back(g);
+        if (n_own) {
+            const unsigned t_count = plan_threads(n);
+            struct Near {
+                uint32_t id;
+                bool in1;
+            };
+            std::vector<std::vector<Near>> part(t_count);
+            parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+                for (size_t g = begin; g < end; ++g) {
+                    if (owner[g] == rank)
+                        continue;
+                    int64_t c[3];
+                    cell_of_key(keys[g], c);
+                    bool in2 = true, in1 = true;
+                    for (int a = 0; a < 3; ++a) {
+                        in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
+                        in1 = in1 && c[a] >= lo[a] - 1 && c[a] <= hi[a] + 1;
+                    }
+                    if (in2)
+                        part[t].push_back(Near{(uint32_t)g, in1});
+                }
+            });
+            for (unsigned t = 0; t < t_count; ++t)
+                for (const Near &f : part[t]) {
+                    int64_t c[3];
+                    cell_of_key(keys[f.id], c);
+                    foreign_cells.insert(keys[f.id]);
+                    for (int a = 0; a < 3; ++a)
+                        layers[a][(size_t)(c[a] - layer0[a])] = 1;
+                    if (f.in1)
+                        candidates.push_back(f.id);
+                }
         }
+        lap("foreign bodies nearby");
         // near1 / near2 [x]: a foreign cell within one / two layers of layer x, along the axis that leaves the smallest share
         // of the box near foreign layers
         int major = 0;
@@ -347,6 +473,7 @@ struct HaloPlanner {
             }
             is_boundary[k] = it->second;
         }
+        lap("rim cells, boundary");
         // a candidate is a ghost iff an own cell lies within one cell of its cell (such an own cell is a rim cell)
         std::unordered_map<int64_t, uint8_t> reached; // foreign cell -> within one cell of an own cell (memoised)
         std::vector<uint32_t> ghost_list;
@@ -365,6 +492,7 @@ struct HaloPlanner {
             if (it->second)
                 ghost_list.push_back(g);
         }
+        lap("ghosts");
         for (uint32_t j = 0; j < n_joints; ++j) {
             const uint32_t a = joints[j].body_a, b = joints[j].body_b;
             const bool own_a = owner[a] == rank, own_b = owner[b] == rank;
@@ -383,6 +511,7 @@ struct HaloPlanner {
         for (uint32_t k = 0; k < n_own; ++k)
             if (is_boundary[k])
                 boundary.push_back(own[k]);
+        lap("joints, lists");
         if (far) {
             // an own body with a foreign cell within two cells of its own (or a boundary body) is not far
             far->assign(n_own, 0);
@@ -409,6 +538,7 @@ struct HaloPlanner {
                 }
             }
         }
+        lap("far bodies");
     }
 };
 
@@ -796,14 +926,8 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
     uint64_t migrated = 0;
     if (st.ok()) {
         std::vector<Cut> cuts;
-        int axes[3];
-        slab_axes(keys.data(), n, axes);
-        std::vector<int64_t> slab(n);
-        for (uint32_t g = 0; g < n; ++g)
-            slab[g] = slab_key(keys[g], axes);
-        partition_cuts(slab.data(), n, w, cuts);
+        compute_owners(keys.data(), n, w, owner.data(), cuts);
         for (uint32_t g = 0; g < n; ++g) {
-            owner[g] = (uint8_t)owner_of(cuts, slab[g], g);
             ++owned_count[owner[g]];
             migrated += owner[g] != holder[g];
         }
@@ -1850,14 +1974,7 @@ int xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n_
     if ((n_global && (!cell_keys || !owner)) || n_ranks == 0 || n_ranks > 64)
         return set_error(XPBD_E_INVALID, "xpbd_halo_partition: bad argument");
     std::vector<Cut> cuts;
-    int axes[3];
-    slab_axes(cell_keys, n_global, axes);
-    std::vector<int64_t> slab(n_global);
-    for (uint32_t g = 0; g < n_global; ++g)
-        slab[g] = slab_key(cell_keys[g], axes);
-    partition_cuts(slab.data(), n_global, n_ranks, cuts);
-    for (uint32_t g = 0; g < n_global; ++g)
-        owner[g] = (uint8_t)owner_of(cuts, slab[g], g);
+    compute_owners(cell_keys, n_global, n_ranks, owner, cuts);
     return XPBD_OK;
 }
 
