@@ -96,8 +96,9 @@ hipError_t launch_edge_axes_reference(const BodyArrays &b, const PolytopeTables 
 // shapes (small-small, large-small, large-large): class 0 fills the first n_pairs entries from the front, class 1 from
 // the back, class 2 the second n_pairs entries from the front.
 //
-// `axis_cache` (n_pairs uint16, or null): the face axis that separated a pair the last time the SAT looked at it --
-// 0 = none, else 1 + 2 * face + (0: a face of A, 1: of B).  A pair of a settled pile that is separated by a face axis in
+// `axis_cache` (n_pairs uint16, or null): the axis that separated a pair the last time the SAT looked at it --
+// 0 = none, 1 + 2 * face + (0: a face of A, 1: of B), or 0x8000 | q for edge axis q (direction of A x direction of B in the
+// SAT's numbering; round 3).  A pair of a settled pile that is separated by a face axis in
 // one substep is separated by the SAME axis in the next 99 times in 100 (scripts/separated_pair_census.py), and more
 // than half of a pile's neighbour pairs are such pairs.  The pre-test pass therefore evaluates the cached face query
 // first -- exactly the arithmetic the full SAT would do for that face, so the verdict "separated" is the SAT's own --

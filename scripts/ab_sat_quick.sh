@@ -1,0 +1,10 @@
+#!/bin/bash
+# boxes pile + mixed pile (SAT) with the current build (or $XPBD_HIP_LIB): value and the SAT / pre-test kernel times.
+# Usage: scripts/ab_sat_quick.sh <tag>   -> gpurun_out/<tag>/
+set -o pipefail
+OUT=gpurun_out/$1; mkdir -p "$OUT"; export TMPDIR=/tmp
+for s in boxes_pile_262144_sat mixed_pile_65536_sat; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$s" -- python3 bench.py --steps 20 --warmup 5 --only $s > "$OUT/bench_$s.json" 2> "$OUT/trace_$s.log"
+  raw=$(find "$OUT/trace_$s" -name "*kernel_trace.csv" | head -1); python3 scripts/timed_region_kernels.py $raw > "$OUT/timed_$s.json"
+done
+find "$OUT" -name "*kernel_trace.csv" -delete
