@@ -60,6 +60,27 @@ def test_sharded_equals_single_device_and_oracle(n_ranks, through_device):
     assert bits_equal(got, expected(ob, bodies, sid, kind, substeps, frames, 0.02))
 
 
+@pytest.mark.parametrize("which", ["every third body", "one shard's side only"])
+def test_sharded_bodies_of_one_shape_with_different_masses(which):
+    """Bodies of ONE shape with different mass properties: a world keeps the mass properties per shape while all bodies of a
+    shape share them bit for bit (xpbd_world.cpp: stat_shared) and per body otherwise.  The re-plans re-pack the shards on the
+    device and must notice when an ARRIVING body (a ghost, a migrated body) breaks a shard's sharing: heavy bodies everywhere,
+    and heavy bodies at one end of the line only (so that one shard starts with shared properties and learns better from
+    its first ghosts)."""
+    kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 96, 6, 40
+    bodies, sid = line_scene(capi, kind, n, 13, 1.3)
+    order = np.argsort(bodies[:, 31])                                     # along the line the shards are cut across
+    heavy = order[::3] if which == "every third body" else order[: n // 2 - 2]
+    bodies[heavy, 0] *= 0.25                                              # inverse mass / 4 ...
+    bodies[heavy, 1:10] *= 0.25                                           # ... and the inverse inertia with it
+    got, s0, s1, _ = sharded(bodies, sid, kind, 2, frames, substeps, replan_at=(10, 25), auto_replan=True)
+    assert s0["ghosts"] > 0 and s1["plans"] >= 3
+    one, one_stats = single(bodies, sid, kind, frames, substeps)
+    assert one_stats[1] > 0
+    assert bits_equal(got, one)
+    assert bits_equal(got, expected(ob, bodies, sid, kind, substeps, frames, 0.02))
+
+
 def test_sharded_mixed_shapes_carry_their_shape_ids_into_the_ghosts():
     kind, n, substeps, frames = capi.SCENE_MIXED_DROP, 150, 6, 30
     bodies, sid = line_scene(capi, kind, n, 4, 1.4)
