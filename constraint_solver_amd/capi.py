@@ -80,6 +80,7 @@ TRANSPORT_RCCL, TRANSPORT_LOCAL = 0, 1
 MULTI_AUTO_REPLAN = 1
 MULTI_PLAN_THROUGH_DEVICE = 2
 MULTI_SERIAL_ENQUEUE = 4
+MULTI_FULL_PLANS = 8
 
 
 class PolytopeDesc(C.Structure):
@@ -457,7 +458,7 @@ class MultiWorld:
     (EXTENSION; the caller is World::integrate, src/world.rs:34-43)."""
 
     def __init__(self, n_ranks, first_rank=0, devices=(0,), transport=TRANSPORT_RCCL, comm_id=None, pad=0.02, halo_margin=0.5,
-                 narrowphase=NARROWPHASE_SAT, auto_replan=False, plan_through_device=False, serial_enqueue=False):
+                 narrowphase=NARROWPHASE_SAT, auto_replan=False, plan_through_device=False, serial_enqueue=False, full_plans=False):
         L = hip_lib()
         cfg = MultiConfig()
         L.xpbd_multi_config_default(C.byref(cfg))
@@ -466,7 +467,7 @@ class MultiWorld:
         cfg.n_ranks, cfg.first_rank, cfg.n_local, cfg.devices = n_ranks, first_rank, len(devices), self._devices
         cfg.transport, cfg.comm_id = transport, comm_id
         cfg.flags = (MULTI_AUTO_REPLAN if auto_replan else 0) | (MULTI_PLAN_THROUGH_DEVICE if plan_through_device else 0) \
-            | (MULTI_SERIAL_ENQUEUE if serial_enqueue else 0)
+            | (MULTI_SERIAL_ENQUEUE if serial_enqueue else 0) | (MULTI_FULL_PLANS if full_plans else 0)
         cfg.contact_pad, cfg.halo_margin, cfg.narrowphase = pad, halo_margin, narrowphase
         self._h = C.c_void_p()
         _check(L.xpbd_multi_world_create(C.byref(self._h), C.byref(cfg)))
@@ -528,9 +529,10 @@ class MultiWorld:
         """dict: plans, frames undone, bodies that changed owner at the last plan, fewest / most bodies owned by a rank, step
         calls and the host nanoseconds inside them (enqueueing, waiting for the pair counts, waiting for the frame's end), and the
         host nanoseconds spent in plans (creation, re-plans)."""
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 12)()
         _check(hip_lib().xpbd_multi_world_plan_stats(self._h, out))
-        keys = ("plans", "rollbacks", "migrated", "owned_min", "owned_max", "steps", "ns_enqueue", "ns_wait_broadphase", "ns_wait_frame", "ns_plan")
+        keys = ("plans", "rollbacks", "migrated", "owned_min", "owned_max", "steps", "ns_enqueue", "ns_wait_broadphase", "ns_wait_frame", "ns_plan",
+                "full_plans", "light_plans")
         return dict(zip(keys, (int(x) for x in out)))
 
     def owners(self):

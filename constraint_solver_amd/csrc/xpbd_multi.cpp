@@ -218,12 +218,12 @@ int64_t slab_key(int64_t key, const int order[3])
 // position t_r of the sorted sequence is found without sorting it: a histogram of the bodies per LAYER (the slab key's
 // leading coordinate, the one the slabs are cut across) locates the layer position t_r falls in, and only that layer's
 // bodies are gathered and sorted (a 1024-layer world: a thousandth of the bodies per cut).
-void compute_owners(const int64_t *keys, uint32_t n, uint32_t w, uint8_t *owner, std::vector<Cut> &cuts)
+void compute_owners(const int64_t *keys, uint32_t n, uint32_t w, uint8_t *owner, std::vector<Cut> &cuts, int axes[3])
 {
     cuts.assign(w, Cut{INT64_MIN, 0});
+    axes[0] = 0, axes[1] = 1, axes[2] = 2;
     if (n == 0)
         return;
-    int axes[3];
     int64_t lo[3], hi[3];
     slab_axes(keys, n, axes, lo, hi);
     std::vector<int64_t> slab(n);
@@ -317,72 +317,73 @@ void compute_owners(const int64_t *keys, uint32_t n, uint32_t w, uint8_t *owner,
     });
 }
 
-// Which remote bodies a rank mirrors and which of its own bodies the others mirror; a pure function of the global cell
-// keys, the owners and the joints, so every rank computes consistent plans.
-struct HaloPlanner {
-    uint32_t n = 0, w = 0;
-    const int64_t *keys = nullptr;
-    const uint8_t *owner = nullptr; // [n] rank owning body g
+uint32_t owner_of(const std::vector<Cut> &cuts, int64_t slab, uint32_t id)
+{
+    // number of cuts <= (key, id), minus one; cuts[0] is the smallest pair
+    uint32_t lo = 0, hi = (uint32_t)cuts.size(); // cuts[lo] <= pair < cuts[hi]
+    const Cut me{slab, id};
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (cuts[mid] <= me)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
 
-    // own:      the rank's bodies (ascending)
-    // ghosts:   remote bodies in a cell within one cell of a cell this rank owns a body in (ascending);
-    // boundary: this rank's bodies in a cell within one cell of a cell another rank owns a body in (ascending).
-    // A joint between an owned and a remote body puts the remote one among the ghosts and the owned one on the boundary.
-    // far (optional, one flag per owned body): no cell within two cells of the body's holds a foreign body.  Such a body
-    // may travel halo_margin + edge / 2 before it can meet a body this rank does not mirror (any foreign body starts more
-    // than two cell edges away, and 2 * (margin + edge / 2) = edge + 2 * margin is less than the 2 * edge - 2 r - pad the
-    // two would have to close), the others halo_margin.
-    // Cost: one pass over ALL cell keys that only decodes them; everything hashed lies within two cells of this rank's
-    // bounding box (the foreign cells next to the slab) or belongs to the rank itself.
-    void plan_rank(uint32_t rank, const xpbd_joint *joints, uint32_t n_joints, std::vector<uint32_t> &own, std::vector<uint32_t> &ghosts,
-                   std::vector<uint32_t> &boundary, std::vector<uint8_t> *far = nullptr) const
+// Which remote bodies a rank mirrors and which of its own bodies the others mirror; a pure function of the cell keys, the
+// owners and the joints, so every rank computes consistent plans.
+//   ghosts:   remote bodies in a cell within one cell of a cell this rank owns a body in (ascending);
+//   boundary: this rank's bodies in a cell within one cell of a cell another rank owns a body in (ascending).
+//   A joint between an owned and a remote body puts the remote one among the ghosts and the owned one on the boundary.
+//   far (optional, one flag per owned body): no cell within two cells of the body's holds a foreign body.  Such a body
+//   may travel halo_margin + edge / 2 before it can meet a body this rank does not mirror (any foreign body starts more
+//   than two cell edges away, and 2 * (margin + edge / 2) = edge + 2 * margin is less than the 2 * edge - 2 r - pad the
+//   two would have to close), the others halo_margin.
+struct HaloPlanner {
+    struct Foreign {
+        uint32_t id;
+        int64_t key;
+    };
+    struct CrossJoint { // a joint between one of the rank's bodies and a remote one
+        uint32_t own_id, remote_id;
+    };
+
+    // The plan from LISTS: the rank's bodies (ascending ids) with their cell keys, the foreign bodies that may matter (any
+    // superset of those within two cells of the box of the rank's cells), the joints that leave the rank.  Everything hashed
+    // lies in the RIM of the rank's box: a per-axis occupancy of foreign cells picks the axis along which the fewest of the
+    // rank's layers have a foreign cell within two layers (the axis the slabs are cut across), and own bodies outside those
+    // layers -- nearly all of a slab -- are classified without a hash lookup.
+    static void plan_lists(const std::vector<uint32_t> &own, const std::vector<int64_t> &own_keys, const std::vector<Foreign> &foreign,
+                           const std::vector<CrossJoint> &cross, std::vector<uint32_t> &ghosts, std::vector<uint32_t> &boundary,
+                           std::vector<uint8_t> *far)
     {
-        own.clear();
-        static const bool trace = std::getenv("XPBD_MULTI_TRACE_PLAN") != nullptr;
-        auto t_lap = std::chrono::steady_clock::now();
-        auto lap = [&](const char *what) {
-            if (trace) {
-                const auto t = std::chrono::steady_clock::now();
-                std::fprintf(stderr, "[xpbd plan_rank %u] %-24s %8.3f ms\n", rank, what, std::chrono::duration<double, std::milli>(t - t_lap).count());
-                t_lap = t;
-            }
-        };
-        // this rank's bodies and the bounding box of their cells (a pass over all bodies: in a few threads, see parallel_chunks)
+        const uint32_t n_own = (uint32_t)own.size();
         int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+        const unsigned t_count = plan_threads(n_own);
         {
-            const unsigned t_count = plan_threads(n);
-            std::vector<std::vector<uint32_t>> part(t_count);
             std::vector<int64_t> box((size_t)t_count * 6);
-            parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+            parallel_chunks(n_own, [&](unsigned t, size_t begin, size_t end) {
                 int64_t l[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, h[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
-                std::vector<uint32_t> &mine = part[t];
-                for (size_t g = begin; g < end; ++g)
-                    if (owner[g] == rank) {
-                        mine.push_back((uint32_t)g);
-                        int64_t c[3];
-                        cell_of_key(keys[g], c);
-                        for (int a = 0; a < 3; ++a) {
-                            l[a] = std::min(l[a], c[a]);
-                            h[a] = std::max(h[a], c[a]);
-                        }
+                for (size_t k = begin; k < end; ++k) {
+                    int64_t c[3];
+                    cell_of_key(own_keys[k], c);
+                    for (int a = 0; a < 3; ++a) {
+                        l[a] = std::min(l[a], c[a]);
+                        h[a] = std::max(h[a], c[a]);
                     }
+                }
                 for (int a = 0; a < 3; ++a)
                     box[(size_t)t * 6 + a] = l[a], box[(size_t)t * 6 + 3 + a] = h[a];
             });
-            for (unsigned t = 0; t < t_count; ++t) {
-                own.insert(own.end(), part[t].begin(), part[t].end());
+            for (unsigned t = 0; t < t_count; ++t)
                 for (int a = 0; a < 3; ++a) {
                     lo[a] = std::min(lo[a], box[(size_t)t * 6 + a]);
                     hi[a] = std::max(hi[a], box[(size_t)t * 6 + 3 + a]);
                 }
-            }
         }
-        const uint32_t n_own = (uint32_t)own.size();
-        lap("own bodies, box");
-        // the foreign bodies within two cells of that box: their cells, and (within one cell of the box) the possible ghosts.
-        // `layers[a]`: per coordinate of the box along axis a, is there a foreign cell?  Along the axis the slabs are cut across
-        // only the ends of the box have any, and own bodies more than two layers from such a coordinate -- nearly all of a
-        // slab -- need no hashing at all.
+        // `layers[a]`: per coordinate of the box along axis a, is there a foreign cell?
         std::vector<uint8_t> layers[3];
         int64_t layer0[3] = {0, 0, 0};
         for (int a = 0; a < 3 && n_own; ++a) {
@@ -390,41 +391,25 @@ struct HaloPlanner {
             layers[a].assign((size_t)(hi[a] - lo[a] + 9), 0);
         }
         std::unordered_set<int64_t> foreign_cells;
-        std::vector<uint32_t> candidates;
-        if (n_own) {
-            const unsigned t_count = plan_threads(n);
-            struct Near {
-                uint32_t id;
-                bool in1;
-            };
-            std::vector<std::vector<Near>> part(t_count);
-            parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
-                for (size_t g = begin; g < end; ++g) {
-                    if (owner[g] == rank)
-                        continue;
-                    int64_t c[3];
-                    cell_of_key(keys[g], c);
-                    bool in2 = true, in1 = true;
-                    for (int a = 0; a < 3; ++a) {
-                        in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
-                        in1 = in1 && c[a] >= lo[a] - 1 && c[a] <= hi[a] + 1;
-                    }
-                    if (in2)
-                        part[t].push_back(Near{(uint32_t)g, in1});
-                }
-            });
-            for (unsigned t = 0; t < t_count; ++t)
-                for (const Near &f : part[t]) {
-                    int64_t c[3];
-                    cell_of_key(keys[f.id], c);
-                    foreign_cells.insert(keys[f.id]);
-                    for (int a = 0; a < 3; ++a)
-                        layers[a][(size_t)(c[a] - layer0[a])] = 1;
-                    if (f.in1)
-                        candidates.push_back(f.id);
-                }
+        std::vector<Foreign> candidates; // foreign bodies inside the box grown by one cell: the possible ghosts
+        for (const Foreign &f : foreign) {
+            if (!n_own)
+                break;
+            int64_t c[3];
+            cell_of_key(f.key, c);
+            bool in2 = true, in1 = true;
+            for (int a = 0; a < 3; ++a) {
+                in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
+                in1 = in1 && c[a] >= lo[a] - 1 && c[a] <= hi[a] + 1;
+            }
+            if (!in2)
+                continue;
+            foreign_cells.insert(f.key);
+            for (int a = 0; a < 3; ++a)
+                layers[a][(size_t)(c[a] - layer0[a])] = 1;
+            if (in1)
+                candidates.push_back(f);
         }
-        lap("foreign bodies nearby");
         // near1 / near2 [x]: a foreign cell within one / two layers of layer x, along the axis that leaves the smallest share
         // of the box near foreign layers
         int major = 0;
@@ -457,52 +442,60 @@ struct HaloPlanner {
         // bodies are boundary bodies)
         std::unordered_map<int64_t, uint8_t> rim_cells;
         std::vector<uint8_t> is_boundary(n_own, 0);
-        for (uint32_t k = 0; k < n_own; ++k) {
+        // (which own bodies lie in layers near foreign ones: a pass over all of them, in a few threads; the hashing below is
+        // for those only)
+        std::vector<std::vector<uint32_t>> rim_part(t_count), near2_part(t_count);
+        parallel_chunks(n_own, [&](unsigned t, size_t begin, size_t end) {
+            for (size_t k = begin; k < end; ++k) {
+                int64_t c[3];
+                cell_of_key(own_keys[k], c);
+                const size_t x = (size_t)(c[major] - layer_base);
+                if (near1[x])
+                    rim_part[t].push_back((uint32_t)k);
+                if (near2[x])
+                    near2_part[t].push_back((uint32_t)k);
+            }
+        });
+        std::vector<uint32_t> rim_list, near2_list;
+        for (unsigned t = 0; t < t_count; ++t) {
+            rim_list.insert(rim_list.end(), rim_part[t].begin(), rim_part[t].end());
+            near2_list.insert(near2_list.end(), near2_part[t].begin(), near2_part[t].end());
+        }
+        for (uint32_t k : rim_list) {
             int64_t c[3];
-            cell_of_key(keys[own[k]], c);
-            if (!near1[(size_t)(c[major] - layer_base)])
-                continue;
-            auto it = rim_cells.find(keys[own[k]]);
+            cell_of_key(own_keys[k], c);
+            auto it = rim_cells.find(own_keys[k]);
             if (it == rim_cells.end()) {
                 bool seen = false;
                 for (int dx = -1; dx <= 1 && !seen; ++dx)
                     for (int dy = -1; dy <= 1 && !seen; ++dy)
                         for (int dz = -1; dz <= 1 && !seen; ++dz)
                             seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
-                it = rim_cells.emplace(keys[own[k]], seen).first;
+                it = rim_cells.emplace(own_keys[k], seen).first;
             }
             is_boundary[k] = it->second;
         }
-        lap("rim cells, boundary");
         // a candidate is a ghost iff an own cell lies within one cell of its cell (such an own cell is a rim cell)
         std::unordered_map<int64_t, uint8_t> reached; // foreign cell -> within one cell of an own cell (memoised)
         std::vector<uint32_t> ghost_list;
-        for (uint32_t g : candidates) {
-            auto it = reached.find(keys[g]);
+        for (const Foreign &f : candidates) {
+            auto it = reached.find(f.key);
             if (it == reached.end()) {
                 int64_t c[3];
-                cell_of_key(keys[g], c);
+                cell_of_key(f.key, c);
                 bool near = false;
                 for (int dx = -1; dx <= 1 && !near; ++dx)
                     for (int dy = -1; dy <= 1 && !near; ++dy)
                         for (int dz = -1; dz <= 1 && !near; ++dz)
                             near = rim_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
-                it = reached.emplace(keys[g], near).first;
+                it = reached.emplace(f.key, near).first;
             }
             if (it->second)
-                ghost_list.push_back(g);
+                ghost_list.push_back(f.id);
         }
-        lap("ghosts");
-        for (uint32_t j = 0; j < n_joints; ++j) {
-            const uint32_t a = joints[j].body_a, b = joints[j].body_b;
-            const bool own_a = owner[a] == rank, own_b = owner[b] == rank;
-            if (own_a && !own_b) {
-                ghost_list.push_back(b);
-                is_boundary[std::lower_bound(own.begin(), own.end(), a) - own.begin()] = 1;
-            } else if (own_b && !own_a) {
-                ghost_list.push_back(a);
-                is_boundary[std::lower_bound(own.begin(), own.end(), b) - own.begin()] = 1;
-            }
+        for (const CrossJoint &j : cross) {
+            ghost_list.push_back(j.remote_id);
+            is_boundary[std::lower_bound(own.begin(), own.end(), j.own_id) - own.begin()] = 1;
         }
         std::sort(ghost_list.begin(), ghost_list.end());
         ghost_list.erase(std::unique(ghost_list.begin(), ghost_list.end()), ghost_list.end());
@@ -511,34 +504,104 @@ struct HaloPlanner {
         for (uint32_t k = 0; k < n_own; ++k)
             if (is_boundary[k])
                 boundary.push_back(own[k]);
-        lap("joints, lists");
         if (far) {
             // an own body with a foreign cell within two cells of its own (or a boundary body) is not far
             far->assign(n_own, 0);
             const size_t limit = 20000; // beyond that many foreign cells around the slab the test is not worth it: nobody is far
             if (n_own && foreign_cells.size() <= limit) {
                 std::unordered_map<int64_t, uint8_t> near_cells; // own cell in a layer near foreign ones -> a foreign cell within two cells
-                for (uint32_t k = 0; k < n_own; ++k) {
+                for (uint32_t k = 0; k < n_own; ++k) // (outside those layers: far unless a joint made it a boundary body)
+                    (*far)[k] = !is_boundary[k];
+                for (uint32_t k : near2_list) {
                     int64_t c[3];
-                    cell_of_key(keys[own[k]], c);
-                    if (!near2[(size_t)(c[major] - layer_base)]) {
-                        (*far)[k] = !is_boundary[k];
-                        continue;
-                    }
-                    auto it = near_cells.find(keys[own[k]]);
+                    cell_of_key(own_keys[k], c);
+                    auto it = near_cells.find(own_keys[k]);
                     if (it == near_cells.end()) {
                         bool seen = false;
                         for (int dx = -2; dx <= 2 && !seen; ++dx)
                             for (int dy = -2; dy <= 2 && !seen; ++dy)
                                 for (int dz = -2; dz <= 2 && !seen; ++dz)
                                     seen = foreign_cells.count(cell_key(c[0] + dx, c[1] + dy, c[2] + dz)) != 0;
-                        it = near_cells.emplace(keys[own[k]], seen).first;
+                        it = near_cells.emplace(own_keys[k], seen).first;
                     }
                     (*far)[k] = !it->second && !is_boundary[k];
                 }
             }
         }
-        lap("far bodies");
+    }
+
+    // ... and from the cell keys and owners of ALL bodies (a full plan, the host-only diagnostics): two passes over the world
+    // (in a few threads, see parallel_chunks) collect the rank's bodies and the foreign bodies within two cells of their box.
+    uint32_t n = 0, w = 0;
+    const int64_t *keys = nullptr;
+    const uint8_t *owner = nullptr; // [n] rank owning body g
+
+    void plan_rank(uint32_t rank, const xpbd_joint *joints, uint32_t n_joints, std::vector<uint32_t> &own, std::vector<uint32_t> &ghosts,
+                   std::vector<uint32_t> &boundary, std::vector<uint8_t> *far = nullptr) const
+    {
+        own.clear();
+        std::vector<int64_t> own_keys;
+        int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+        const unsigned t_count = plan_threads(n);
+        {
+            std::vector<std::vector<uint32_t>> part(t_count);
+            std::vector<int64_t> box((size_t)t_count * 6);
+            parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+                int64_t l[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, h[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+                std::vector<uint32_t> &mine = part[t];
+                for (size_t g = begin; g < end; ++g)
+                    if (owner[g] == rank) {
+                        mine.push_back((uint32_t)g);
+                        int64_t c[3];
+                        cell_of_key(keys[g], c);
+                        for (int a = 0; a < 3; ++a) {
+                            l[a] = std::min(l[a], c[a]);
+                            h[a] = std::max(h[a], c[a]);
+                        }
+                    }
+                for (int a = 0; a < 3; ++a)
+                    box[(size_t)t * 6 + a] = l[a], box[(size_t)t * 6 + 3 + a] = h[a];
+            });
+            for (unsigned t = 0; t < t_count; ++t) {
+                own.insert(own.end(), part[t].begin(), part[t].end());
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::min(lo[a], box[(size_t)t * 6 + a]);
+                    hi[a] = std::max(hi[a], box[(size_t)t * 6 + 3 + a]);
+                }
+            }
+        }
+        own_keys.resize(own.size());
+        for (size_t k = 0; k < own.size(); ++k)
+            own_keys[k] = keys[own[k]];
+        std::vector<Foreign> foreign;
+        if (!own.empty()) {
+            std::vector<std::vector<Foreign>> part(t_count);
+            parallel_chunks(n, [&](unsigned t, size_t begin, size_t end) {
+                for (size_t g = begin; g < end; ++g) {
+                    if (owner[g] == rank)
+                        continue;
+                    int64_t c[3];
+                    cell_of_key(keys[g], c);
+                    bool in2 = true;
+                    for (int a = 0; a < 3; ++a)
+                        in2 = in2 && c[a] >= lo[a] - 2 && c[a] <= hi[a] + 2;
+                    if (in2)
+                        part[t].push_back(Foreign{(uint32_t)g, keys[g]});
+                }
+            });
+            for (unsigned t = 0; t < t_count; ++t)
+                foreign.insert(foreign.end(), part[t].begin(), part[t].end());
+        }
+        std::vector<CrossJoint> cross;
+        for (uint32_t j = 0; j < n_joints; ++j) {
+            const uint32_t a = joints[j].body_a, b = joints[j].body_b;
+            const bool own_a = owner[a] == rank, own_b = owner[b] == rank;
+            if (own_a && !own_b)
+                cross.push_back(CrossJoint{a, b});
+            else if (own_b && !own_a)
+                cross.push_back(CrossJoint{b, a});
+        }
+        plan_lists(own, own_keys, foreign, cross, ghosts, boundary, far);
     }
 };
 
@@ -625,6 +688,11 @@ struct xpbd_multi_world {
     double cell_edge = 0.0;
     double rmax_local = 0.0;          // largest bounding radius (r_shape + |centroid - com|) among the bodies this process handed over
     std::vector<int32_t> slot_of;     // [n_global] scratch of a plan: local slot of a body, -1 outside the shard being built
+    std::vector<uint32_t> joint_off, joint_adj; // [n_global + 1], [2 * joints]: the joints at every body (indices into `joints`, ascending)
+    std::vector<Cut> cuts;            // the cuts of the last full plan, kept by the light plans between (cuts_valid)
+    int cut_axes[3] = {0, 1, 2};      // ... over slab keys packed in this order of the axes
+    bool cuts_valid = false, check_plans = false;
+    uint64_t full_plans = 0, light_plans = 0;
     double last_displacement = 0.0; // the largest fraction of its travel allowance any body had used at the last check, times halo_margin
     Workers *workers = nullptr;     // one enqueueing thread per local shard (n_local > 1), started by the first step
     bool all_local() const { return shards.size() == n_ranks; }
@@ -829,81 +897,69 @@ struct KeyRow {
     uint32_t id, unused;
 };
 
-// Builds ownership and halos from the bodies the shards own AT THE MOMENT (the first time: the index slices the caller handed
-// over, uploaded as they are) and re-packs every shard's local world.  The bodies stay on the device: what crosses the bus
-// is 8 bytes of cell key per owned body, the records of the bodies that change hands or are mirrored (a few per cent) and
-// the index lists of the new plan.  Collective.  Local failures are carried through the collectives (LocalStatus: `st` may
-// already hold one), so all ranks fail together.
-int make_plan(xpbd_multi_world *mw, LocalStatus &st)
+// XPBD_MULTI_TRACE_PLAN=1: the host time of every phase of a plan on stderr
+struct PlanTrace {
+    uint64_t plan = 0, t_last = 0;
+    bool on = false;
+    explicit PlanTrace(uint64_t plan_index) : plan(plan_index), t_last(now_ns())
+    {
+        static const bool trace = std::getenv("XPBD_MULTI_TRACE_PLAN") != nullptr;
+        on = trace;
+    }
+    void lap(const char *what)
+    {
+        if (on) {
+            const uint64_t t = now_ns();
+            std::fprintf(stderr, "[xpbd plan %llu] %-28s %8.3f ms\n", (unsigned long long)plan, what, (double)(t - t_last) * 1e-6);
+            t_last = t;
+        }
+    }
+};
+
+// The new plan of one local shard, besides Shard::ghosts / boundary / far: what it will own (ascending ids) and who holds
+// those bodies now, who owns and who holds its ghosts, what it hands out (bodies that change owner, bodies others mirror).
+struct ShardPlan {
+    std::vector<uint32_t> own, exports;
+    std::vector<uint8_t> own_holder, ghost_owner, ghost_holder;
+};
+
+// The cell keys of the bodies every local shard holds, computed where the bodies are (8 bytes per body come back).
+int held_cell_keys(xpbd_multi_world *mw, LocalStatus &st, double edge, std::vector<std::vector<int64_t>> &held_keys)
+{
+    held_keys.assign(mw->shards.size(), std::vector<int64_t>());
+    for (size_t k = 0; k < mw->shards.size(); ++k) {
+        Shard &s = mw->shards[k];
+        const uint32_t cnt = (uint32_t)s.held_ids.size();
+        held_keys[k].assign(cnt, 0);
+        uint32_t bad = UINT32_MAX;
+        if (st.ok())
+            st.keep(xpbd::halo_cell_keys(s.world, s.owned_slots.as<uint32_t>(), cnt, edge, held_keys[k].data(), &bad));
+        if (st.ok() && bad != UINT32_MAX)
+            st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u has a non-finite position: it cannot be placed in the grid the shards "
+                                              "are cut from", s.held_ids[bad]));
+    }
+    return XPBD_OK;
+}
+
+// One all-gather of 16 bytes per body: the cell key of every body of the world and who holds it.
+int gather_world_keys(xpbd_multi_world *mw, LocalStatus &st, const std::vector<std::vector<int64_t>> &held_keys, uint64_t max_held,
+                      std::vector<int64_t> &keys, std::vector<uint8_t> &holder)
 {
     const uint32_t n = mw->n_global, w = mw->n_ranks;
     const size_t n_local = mw->shards.size();
-    std::vector<uint8_t> gathered;
-    std::vector<const void *> send(n_local);
-    const uint64_t t_plan = now_ns();
-    // XPBD_MULTI_TRACE_PLAN=1: the host time of every phase of a plan on stderr
-    static const bool trace = std::getenv("XPBD_MULTI_TRACE_PLAN") != nullptr;
-    uint64_t t_lap = t_plan;
-    auto lap = [&](const char *what) {
-        if (trace) {
-            const uint64_t t = now_ns();
-            std::fprintf(stderr, "[xpbd plan %llu] %-28s %8.3f ms\n", (unsigned long long)mw->plans, what, (double)(t - t_lap) * 1e-6);
-            t_lap = t;
-        }
-    };
-
-    // 1. the largest bounding radius of the whole world (r_shape + |centroid - com|: conservative whatever the rotation;
-    //    a property of the bodies, known since the upload) and how many bodies every rank owns
-    struct Head {
-        double rmax;
-        uint64_t count;
-    };
-    std::vector<Head> head(n_local);
-    for (size_t k = 0; k < n_local; ++k) {
-        head[k] = Head{mw->rmax_local, mw->shards[k].held_ids.size()};
-        send[k] = &head[k];
-    }
-    MW_TRY(all_gather_host(mw, send, sizeof(Head), gathered, st));
-    double rmax = 0.0;
-    uint64_t max_held = 0, total_held = 0;
-    for (uint32_t r = 0; r < w; ++r) {
-        Head h;
-        std::memcpy(&h, gathered.data() + (size_t)r * sizeof(Head), sizeof h);
-        rmax = std::max(rmax, h.rmax);
-        max_held = std::max(max_held, h.count);
-        total_held += h.count;
-    }
-    const double edge = 2.0 * (rmax + mw->pad + mw->margin);
-    if (!(edge > 0.0) || !(edge <= 1.0e300))
-        st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: cell edge %g from radius %g, pad %g, halo_margin %g", edge, rmax, mw->pad, mw->margin));
-    if (total_held != n)
-        st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: the ranks hold %llu bodies together, the world has %u", (unsigned long long)total_held, n));
-
-    // 2. grid cell of every body of the world (centre = position + center_of_mass; computed where the bodies are, 8 bytes per
-    //    body come back), one all-gather of 16 bytes per body: key, global id
     std::vector<std::vector<KeyRow>> key_rows(n_local);
-    {
-        std::vector<int64_t> own_keys;
-        for (size_t k = 0; k < n_local; ++k) {
-            Shard &s = mw->shards[k];
-            const uint32_t cnt = (uint32_t)s.held_ids.size();
-            key_rows[k].assign(max_held, KeyRow{0, UINT32_MAX, 0});
-            own_keys.assign(cnt, 0);
-            uint32_t bad = UINT32_MAX;
-            if (st.ok())
-                st.keep(xpbd::halo_cell_keys(s.world, s.owned_slots.as<uint32_t>(), cnt, edge, own_keys.data(), &bad));
-            if (st.ok() && bad != UINT32_MAX)
-                st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u has a non-finite position: it cannot be placed in the grid the shards "
-                                                  "are cut from", s.held_ids[bad]));
-            for (uint32_t i = 0; i < cnt && st.ok(); ++i)
-                key_rows[k][i] = KeyRow{own_keys[i], s.held_ids[i], 0};
-            send[k] = key_rows[k].data();
-        }
+    std::vector<const void *> send(n_local);
+    std::vector<uint8_t> gathered;
+    for (size_t k = 0; k < n_local; ++k) {
+        const Shard &s = mw->shards[k];
+        key_rows[k].assign(max_held, KeyRow{0, UINT32_MAX, 0});
+        for (size_t i = 0; i < s.held_ids.size() && st.ok(); ++i)
+            key_rows[k][i] = KeyRow{held_keys[k][i], s.held_ids[i], 0};
+        send[k] = key_rows[k].data();
     }
-    lap("cell keys (device)");
     MW_TRY(all_gather_host(mw, send, (size_t)max_held * sizeof(KeyRow), gathered, st));
-    std::vector<int64_t> keys(n, 0);
-    std::vector<uint8_t> holder(n, 0xFF);
+    keys.assign(n, 0);
+    holder.assign(n, 0xFF);
     for (uint32_t r = 0; r < w && st.ok(); ++r) {
         const KeyRow *rows = reinterpret_cast<const KeyRow *>(gathered.data() + (size_t)r * max_held * sizeof(KeyRow));
         for (uint64_t i = 0; i < max_held; ++i) {
@@ -917,35 +973,17 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
             holder[rows[i].id] = (uint8_t)r;
         }
     }
-    lap("keys of the world");
+    return XPBD_OK;
+}
 
-    // 3. ownership: the cell sequence (longest axis first) cut into runs of near-equal body count; then who mirrors whom
-    std::vector<uint8_t> owner(n, 0);
-    std::vector<uint32_t> owned_count(w, 0);
-    std::vector<std::vector<uint32_t>> own(n_local), exports(n_local);
-    uint64_t migrated = 0;
-    if (st.ok()) {
-        std::vector<Cut> cuts;
-        compute_owners(keys.data(), n, w, owner.data(), cuts);
-        for (uint32_t g = 0; g < n; ++g) {
-            ++owned_count[owner[g]];
-            migrated += owner[g] != holder[g];
-        }
-        lap("cuts, owners");
-        HaloPlanner planner;
-        planner.n = n, planner.w = w, planner.keys = keys.data(), planner.owner = owner.data();
-        for (size_t k = 0; k < n_local; ++k) {
-            Shard &s = mw->shards[k];
-            planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), own[k], s.ghosts, s.boundary, &s.far);
-            // what this shard holds and somebody else needs: bodies that change owner, and its (remaining) bodies that others mirror
-            for (uint32_t g : s.held_ids)
-                if (owner[g] != s.rank || std::binary_search(s.boundary.begin(), s.boundary.end(), g))
-                    exports[k].push_back(g);
-        }
-    }
-    mw->cell_edge = edge;
-    lap("halo plans");
-
+// The second half of every plan: the boundary lists of all ranks fix the rows of the per-substep all-gather, the records of
+// the bodies that change hands or are mirrored travel, and every shard's local world is re-packed on its device.  Collective.
+int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &plans, double edge, PlanTrace &trace)
+{
+    const uint32_t n = mw->n_global, w = mw->n_ranks;
+    const size_t n_local = mw->shards.size();
+    std::vector<uint8_t> gathered;
+    std::vector<const void *> send(n_local);
     // 4. the boundary lists of all ranks (ascending global ids) fix the rows of the per-substep all-gather; the export lists
     //    those of the plan-time record exchange
     struct Counts {
@@ -953,7 +991,7 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
     };
     std::vector<Counts> mine(n_local), counts(w);
     for (size_t k = 0; k < n_local; ++k) {
-        mine[k] = Counts{(uint32_t)mw->shards[k].boundary.size(), (uint32_t)exports[k].size()};
+        mine[k] = Counts{(uint32_t)mw->shards[k].boundary.size(), (uint32_t)plans[k].exports.size()};
         send[k] = &mine[k];
     }
     MW_TRY(all_gather_host(mw, send, sizeof(Counts), gathered, st));
@@ -986,7 +1024,7 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
         for (size_t k = 0; k < n_local; ++k) {
             pad_list[k].assign(cap_exp, 0xFFFFFFFFu);
             if (st.ok())
-                std::copy(exports[k].begin(), exports[k].end(), pad_list[k].begin());
+                std::copy(plans[k].exports.begin(), plans[k].exports.end(), pad_list[k].begin());
             send[k] = pad_list[k].data();
         }
         MW_TRY(all_gather_host(mw, send, (size_t)cap_exp * 4, gathered, st));
@@ -998,7 +1036,7 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
             pad_rec[k].assign((size_t)cap_exp * kRecord, 0.0);
             slots.clear();
             if (st.ok())
-                for (uint32_t g : exports[k])
+                for (uint32_t g : plans[k].exports)
                     slots.push_back(s.owned_slots_h[std::lower_bound(s.held_ids.begin(), s.held_ids.end(), g) - s.held_ids.begin()]);
             if (st.ok())
                 st.keep(xpbd::download_records(s.world, slots.data(), (uint32_t)slots.size(), pad_rec[k].data()));
@@ -1008,15 +1046,14 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
         exp_records.resize((size_t)w * cap_exp * kRecord);
         std::memcpy(exp_records.data(), gathered.data(), exp_records.size() * 8);
     }
-    lap("lists, exported records");
+    trace.lap("lists, exported records");
 
     // 5. every shard's local world: owned + ghost bodies in ascending global id.  A body the shard owned before and still
     //    owns moves on the device; a body that arrives (a new owner, a ghost) comes from its holder's exported record.
     const uint32_t rows = mw->rows_per_rank();
-    auto exported = [&](const Shard &me, uint32_t g) -> const double * {
-        const uint32_t h = holder[g];
-        const uint32_t *lo = exp_lists.data() + (size_t)h * cap_exp, *hi = lo + counts[h].exports;
-        const uint32_t *at = std::lower_bound(lo, hi, g);
+    auto exported = [&](const Shard &me, uint32_t g, uint32_t h) -> const double * {
+        const uint32_t *lo = exp_lists.data() + (size_t)h * cap_exp, *hi = h < w ? lo + counts[h].exports : lo;
+        const uint32_t *at = h < w ? std::lower_bound(lo, hi, g) : hi;
         if (at == hi || *at != g) {
             (void)set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is needed by rank %u but not exported by its holder %u (inconsistent plans)", g, me.rank, h);
             return nullptr;
@@ -1027,20 +1064,21 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
         mw->slot_of.assign(n, -1);
     auto build_shard = [&](size_t k) -> int {
         Shard &s = mw->shards[k];
+        ShardPlan &pl = plans[k];
         MW_TRY(bind(s));
-        const uint32_t n_own = (uint32_t)own[k].size(), n_ghost = (uint32_t)s.ghosts.size(), n_loc = n_own + n_ghost;
+        const uint32_t n_own = (uint32_t)pl.own.size(), n_ghost = (uint32_t)s.ghosts.size(), n_loc = n_own + n_ghost;
         std::vector<int32_t> src(n_loc);
         std::vector<double> incoming;
         std::vector<uint32_t> ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(s.boundary.size()), owned_slots(n_own);
         std::vector<uint32_t> local_ids(n_loc);
         uint32_t slot = 0, oi = 0, gi = 0, n_in = 0;
-        size_t old = 0; // walks the bodies owned so far (ascending, like own[k])
+        size_t old = 0; // walks the bodies owned so far (ascending, like pl.own)
         while (oi < n_own || gi < n_ghost) {
-            const bool take_own = gi >= n_ghost || (oi < n_own && own[k][oi] < s.ghosts[gi]);
-            const uint32_t g = take_own ? own[k][oi] : s.ghosts[gi];
+            const bool take_own = gi >= n_ghost || (oi < n_own && pl.own[oi] < s.ghosts[gi]);
+            const uint32_t g = take_own ? pl.own[oi] : s.ghosts[gi];
             local_ids[slot] = g;
             bool here = false;
-            if (take_own && holder[g] == s.rank) {
+            if (take_own && pl.own_holder[oi] == s.rank) {
                 while (old < s.held_ids.size() && s.held_ids[old] < g)
                     ++old;
                 if (old == s.held_ids.size() || s.held_ids[old] != g)
@@ -1049,7 +1087,7 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
                 here = true;
             }
             if (!here) {
-                const double *rec = exported(s, g);
+                const double *rec = exported(s, g, take_own ? pl.own_holder[oi] : pl.ghost_holder[gi]);
                 if (!rec)
                     return XPBD_E_HIP;
                 incoming.insert(incoming.end(), rec, rec + kRecord);
@@ -1058,8 +1096,8 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
             if (take_own) {
                 owned_slots[oi++] = slot;
             } else {
-                const uint32_t o = owner[g];
-                const uint32_t *lo = &lists[(size_t)o * cap], *hi = lo + counts[o].boundary;
+                const uint32_t o = pl.ghost_owner[gi];
+                const uint32_t *lo = &lists[(size_t)(o < w ? o : 0) * cap], *hi = o < w ? lo + counts[o].boundary : lo;
                 const uint32_t *at = std::lower_bound(lo, hi, g);
                 if (at == hi || *at != g)
                     return set_error(XPBD_E_HIP, "xpbd_multi_world: body %u is mirrored by rank %u but not exported by its owner %u (inconsistent plans)", g, s.rank, o);
@@ -1070,30 +1108,40 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
             ++slot;
         }
         for (size_t q = 0; q < s.boundary.size(); ++q)
-            boundary_slots[q] = owned_slots[std::lower_bound(own[k].begin(), own[k].end(), s.boundary[q]) - own[k].begin()];
-        lap("  source map of a shard");
+            boundary_slots[q] = owned_slots[std::lower_bound(pl.own.begin(), pl.own.end(), s.boundary[q]) - pl.own.begin()];
+        trace.lap("  source map of a shard");
         if (int rc = xpbd::repack_bodies(s.world, src.data(), n_loc, incoming.data(), n_in))
             return rc;
-        lap("  re-pack on the device");
-        // joints whose two bodies are both present here, in global joint order, re-indexed to local slots
+        trace.lap("  re-pack on the device");
+        // joints whose two bodies are both present here, in global joint order, re-indexed to local slots: the joints of the
+        // local bodies through the per-body joint lists (a joint is taken at its lower-numbered end)
         for (uint32_t q = 0; q < n_loc; ++q)
             mw->slot_of[local_ids[q]] = (int32_t)q;
-        std::vector<xpbd_joint> local_joints;
-        for (const xpbd_joint &j : mw->joints) {
-            const int32_t a = mw->slot_of[j.body_a], b = mw->slot_of[j.body_b];
-            if (a < 0 || b < 0)
-                continue;
-            xpbd_joint l = j;
-            l.body_a = (uint32_t)a;
-            l.body_b = (uint32_t)b;
-            local_joints.push_back(l);
+        std::vector<uint32_t> joint_ids;
+        for (uint32_t q = 0; q < n_loc; ++q) {
+            const uint32_t g = local_ids[q];
+            for (uint32_t e = mw->joint_off[g]; e < mw->joint_off[g + 1]; ++e) {
+                const xpbd_joint &j = mw->joints[mw->joint_adj[e]];
+                const uint32_t other = j.body_a == g ? j.body_b : j.body_a;
+                if (mw->slot_of[other] >= 0 && (g < other || (g == other && j.body_a == g)))
+                    joint_ids.push_back(mw->joint_adj[e]);
+            }
+        }
+        std::sort(joint_ids.begin(), joint_ids.end());
+        joint_ids.erase(std::unique(joint_ids.begin(), joint_ids.end()), joint_ids.end());
+        std::vector<xpbd_joint> local_joints(joint_ids.size());
+        for (size_t q = 0; q < joint_ids.size(); ++q) {
+            xpbd_joint l = mw->joints[joint_ids[q]];
+            l.body_a = (uint32_t)mw->slot_of[l.body_a];
+            l.body_b = (uint32_t)mw->slot_of[l.body_b];
+            local_joints[q] = l;
         }
         for (uint32_t q = 0; q < n_loc; ++q)
             mw->slot_of[local_ids[q]] = -1;
         if (int rc = xpbd_world_set_joints(s.world, local_joints.data(), (uint32_t)local_joints.size()))
             return rc;
         MW_HIP_TRY(hipStreamSynchronize(s.stream));
-        lap("  joints");
+        trace.lap("  joints");
         MW_TRY(upload_vector(s.boundary_slots, boundary_slots, s.stream));
         MW_TRY(upload_vector(s.ghost_slots, ghost_slots, s.stream));
         MW_TRY(upload_vector(s.ghost_rows, ghost_rows, s.stream));
@@ -1122,8 +1170,8 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
         MW_HIP_TRY(hipStreamSynchronize(s.stream)); // the host vectors above go out of scope
         s.owned_slots_h.swap(owned_slots);
         s.local_ids.swap(local_ids);
-        s.held_ids.swap(own[k]); // from now on the shard holds what it owns
-        lap("  index lists of a shard");
+        s.held_ids.swap(pl.own); // from now on the shard holds what it owns
+        trace.lap("  index lists of a shard");
         return XPBD_OK;
     };
     for (size_t k = 0; k < n_local && st.ok(); ++k)
@@ -1132,13 +1180,384 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
     for (size_t k = 0; k < n_local; ++k)
         send[k] = nullptr;
     MW_TRY(all_gather_host(mw, send, 0, gathered, st));
-    mw->owner.swap(owner);
-    mw->owned_count.swap(owned_count);
-    mw->migrated = migrated;
+    mw->cell_edge = edge;
     mw->planned = true;
     mw->violated = false;
     mw->last_displacement = 0.0;
     ++mw->plans;
+    return XPBD_OK;
+}
+
+// What a shard holds and somebody else needs: bodies that change owner, and its (remaining) bodies that others mirror.
+// held_owner[i] = new owner of held body i; boundary = the shard's new boundary list (ascending).
+void exports_of(const Shard &s, const std::vector<uint8_t> &held_owner, std::vector<uint32_t> &exports)
+{
+    exports.clear();
+    size_t b = 0;
+    for (size_t i = 0; i < s.held_ids.size(); ++i) {
+        const uint32_t g = s.held_ids[i];
+        while (b < s.boundary.size() && s.boundary[b] < g)
+            ++b;
+        if (held_owner[i] != s.rank || (b < s.boundary.size() && s.boundary[b] == g))
+            exports.push_back(g);
+    }
+}
+
+double plan_cell_edge(const xpbd_multi_world *mw, double rmax) { return 2.0 * (rmax + mw->pad + mw->margin); }
+
+// (rmax of the world, bodies held per rank): the first collective of every plan
+int gather_heads(xpbd_multi_world *mw, LocalStatus &st, double &rmax, uint64_t &max_held)
+{
+    struct Head {
+        double rmax;
+        uint64_t count;
+    };
+    const size_t n_local = mw->shards.size();
+    std::vector<Head> head(n_local);
+    std::vector<const void *> send(n_local);
+    std::vector<uint8_t> gathered;
+    for (size_t k = 0; k < n_local; ++k) {
+        head[k] = Head{mw->rmax_local, mw->shards[k].held_ids.size()};
+        send[k] = &head[k];
+    }
+    MW_TRY(all_gather_host(mw, send, sizeof(Head), gathered, st));
+    rmax = 0.0, max_held = 0;
+    uint64_t total_held = 0;
+    for (uint32_t r = 0; r < mw->n_ranks; ++r) {
+        Head h;
+        std::memcpy(&h, gathered.data() + (size_t)r * sizeof(Head), sizeof h);
+        rmax = std::max(rmax, h.rmax);
+        max_held = std::max(max_held, h.count);
+        total_held += h.count;
+    }
+    const double edge = plan_cell_edge(mw, rmax);
+    if (!(edge > 0.0) || !(edge <= 1.0e300))
+        st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: cell edge %g from radius %g, pad %g, halo_margin %g", edge, rmax, mw->pad, mw->margin));
+    if (total_held != mw->n_global)
+        st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: the ranks hold %llu bodies together, the world has %u", (unsigned long long)total_held,
+                          mw->n_global));
+    return XPBD_OK;
+}
+
+// A FULL plan: ownership re-cut from the cell keys of the whole world (every rank passes over 16 bytes per body of it), halos
+// from the global keys and owners.  The first plan, and whenever the sticky cuts of the light plans have drifted out of balance.
+// The bodies stay on the device: what crosses the bus is 8 bytes of cell key per owned body, the records of the bodies that
+// change hands or are mirrored (a few per cent) and the index lists of the new plan.  Collective.  Local failures are
+// carried through the collectives (LocalStatus: `st` may already hold one), so all ranks fail together.
+int make_plan_full(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace)
+{
+    const uint32_t n = mw->n_global, w = mw->n_ranks;
+    const size_t n_local = mw->shards.size();
+    // 1. the largest bounding radius of the whole world (r_shape + |centroid - com|: conservative whatever the rotation;
+    //    a property of the bodies, known since the upload) and how many bodies every rank owns
+    double rmax = 0.0;
+    uint64_t max_held = 0;
+    MW_TRY(gather_heads(mw, st, rmax, max_held));
+    const double edge = plan_cell_edge(mw, rmax);
+    // 2. grid cell of every body of the world (centre = position + center_of_mass)
+    std::vector<std::vector<int64_t>> held_keys;
+    MW_TRY(held_cell_keys(mw, st, edge, held_keys));
+    trace.lap("cell keys (device)");
+    std::vector<int64_t> keys;
+    std::vector<uint8_t> holder;
+    MW_TRY(gather_world_keys(mw, st, held_keys, max_held, keys, holder));
+    trace.lap("keys of the world");
+
+    // 3. ownership: the cell sequence (longest axis first) cut into runs of near-equal body count; then who mirrors whom
+    std::vector<uint8_t> owner(n, 0);
+    std::vector<uint32_t> owned_count(w, 0);
+    std::vector<ShardPlan> plans(n_local);
+    uint64_t migrated = 0;
+    if (st.ok()) {
+        compute_owners(keys.data(), n, w, owner.data(), mw->cuts, mw->cut_axes);
+        for (uint32_t g = 0; g < n; ++g) {
+            ++owned_count[owner[g]];
+            migrated += owner[g] != holder[g];
+        }
+        trace.lap("cuts, owners");
+        HaloPlanner planner;
+        planner.n = n, planner.w = w, planner.keys = keys.data(), planner.owner = owner.data();
+        std::vector<uint8_t> held_owner;
+        for (size_t k = 0; k < n_local; ++k) {
+            Shard &s = mw->shards[k];
+            ShardPlan &pl = plans[k];
+            planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), pl.own, s.ghosts, s.boundary, &s.far);
+            pl.own_holder.resize(pl.own.size());
+            for (size_t i = 0; i < pl.own.size(); ++i)
+                pl.own_holder[i] = holder[pl.own[i]];
+            pl.ghost_owner.resize(s.ghosts.size());
+            pl.ghost_holder.resize(s.ghosts.size());
+            for (size_t i = 0; i < s.ghosts.size(); ++i)
+                pl.ghost_owner[i] = owner[s.ghosts[i]], pl.ghost_holder[i] = holder[s.ghosts[i]];
+            held_owner.resize(s.held_ids.size());
+            for (size_t i = 0; i < s.held_ids.size(); ++i)
+                held_owner[i] = owner[s.held_ids[i]];
+            exports_of(s, held_owner, pl.exports);
+        }
+    }
+    trace.lap("halo plans");
+    MW_TRY(finish_plan(mw, st, plans, edge, trace));
+    mw->owner.swap(owner);
+    mw->owned_count.swap(owned_count);
+    mw->migrated = migrated;
+    mw->cuts_valid = true;
+    ++mw->full_plans;
+    return XPBD_OK;
+}
+
+// A LIGHT plan: the cuts stay where the last full plan put them, so a body's owner follows from its own cell key, and what a
+// rank must know of the others is the RIM -- the bodies within two layers of a cut (nobody else can lie within two cells of a
+// foreign cell), the bodies that change owner, and the ends of joints that leave their holder.  Host work and traffic are
+// proportional to the rank's own bodies plus the rims, not to the world.  Falls back to a full plan (same collectives on
+// every rank: the decision is taken from gathered data) when the shards have drifted out of balance.
+int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, bool &done)
+{
+    done = false;
+    const uint32_t n = mw->n_global, w = mw->n_ranks;
+    const size_t n_local = mw->shards.size();
+    std::vector<uint8_t> gathered;
+    std::vector<const void *> send(n_local);
+    double rmax = 0.0;
+    uint64_t max_held = 0;
+    MW_TRY(gather_heads(mw, st, rmax, max_held));
+    const double edge = plan_cell_edge(mw, rmax);
+    std::vector<std::vector<int64_t>> held_keys;
+    MW_TRY(held_cell_keys(mw, st, edge, held_keys));
+    trace.lap("cell keys (device)");
+    // the new owner of every held body from the sticky cuts; how many bodies every rank sends to every rank
+    std::vector<std::vector<uint8_t>> held_owner(n_local);
+    std::vector<std::vector<int64_t>> held_slab(n_local);
+    std::vector<std::vector<uint32_t>> tally(n_local, std::vector<uint32_t>(w, 0));
+    for (size_t k = 0; k < n_local; ++k) {
+        const Shard &s = mw->shards[k];
+        held_owner[k].assign(s.held_ids.size(), (uint8_t)s.rank);
+        held_slab[k].assign(s.held_ids.size(), 0);
+        for (size_t i = 0; i < s.held_ids.size() && st.ok(); ++i) {
+            held_slab[k][i] = slab_key(held_keys[k][i], mw->cut_axes);
+            held_owner[k][i] = (uint8_t)owner_of(mw->cuts, held_slab[k][i], s.held_ids[i]);
+            ++tally[k][held_owner[k][i]];
+        }
+        send[k] = tally[k].data();
+    }
+    MW_TRY(all_gather_host(mw, send, (size_t)w * 4, gathered, st));
+    std::vector<uint32_t> owned_count(w, 0);
+    uint64_t migrated = 0;
+    for (uint32_t h = 0; h < w; ++h)
+        for (uint32_t r = 0; r < w; ++r) {
+            uint32_t c;
+            std::memcpy(&c, gathered.data() + ((size_t)h * w + r) * 4, 4);
+            owned_count[r] += c;
+            if (h != r)
+                migrated += c;
+        }
+    {
+        // out of balance (a tenth of a share off): time for new cuts
+        const uint32_t share = std::max(1u, n / w);
+        uint32_t most = 0, least = UINT32_MAX;
+        for (uint32_t c : owned_count) {
+            most = std::max(most, c);
+            least = std::min(least, c);
+        }
+        if (most > share + share / 10 + 8 || least + share / 10 + 8 < share)
+            return XPBD_OK; // (done stays false: the caller makes a full plan; every rank decides alike)
+    }
+    trace.lap("owners from the cuts");
+    // the rim: (key, id, new owner) of the held bodies near a cut, changing owner, or at the end of a joint that leaves the shard
+    // (the other end is held elsewhere, or the two ends get different owners)
+    struct RimRow {
+        int64_t key;
+        uint32_t id;
+        uint8_t owner, pad[3];
+    };
+    std::vector<int64_t> cut_layers;
+    for (uint32_t r = 1; r < w; ++r)
+        if (mw->cuts[r].key != INT64_MAX)
+            cut_layers.push_back((mw->cuts[r].key >> 42) - kCellBias);
+    std::sort(cut_layers.begin(), cut_layers.end());
+    cut_layers.erase(std::unique(cut_layers.begin(), cut_layers.end()), cut_layers.end());
+    auto near_a_cut = [&](int64_t slab) {
+        const int64_t layer = (slab >> 42) - kCellBias;
+        const auto at = std::lower_bound(cut_layers.begin(), cut_layers.end(), layer - 2);
+        return at != cut_layers.end() && *at <= layer + 2;
+    };
+    std::vector<std::vector<RimRow>> rim(n_local);
+    if (mw->slot_of.size() != n)
+        mw->slot_of.assign(n, -1);
+    for (size_t k = 0; k < n_local && st.ok(); ++k) {
+        const Shard &s = mw->shards[k];
+        const bool any_joints = !mw->joints.empty();
+        if (any_joints) // (scratch: where in the held lists a body of this shard sits)
+            for (size_t i = 0; i < s.held_ids.size(); ++i)
+                mw->slot_of[s.held_ids[i]] = (int32_t)i;
+        for (size_t i = 0; i < s.held_ids.size(); ++i) {
+            const uint32_t g = s.held_ids[i];
+            bool publish = held_owner[k][i] != s.rank || near_a_cut(held_slab[k][i]);
+            for (uint32_t e = mw->joint_off[g]; e < mw->joint_off[g + 1] && !publish; ++e) {
+                const xpbd_joint &j = mw->joints[mw->joint_adj[e]];
+                const int32_t at = mw->slot_of[j.body_a == g ? j.body_b : j.body_a];
+                // the other end lives elsewhere now, or will: this end's owner (or mirror) must learn about both
+                publish = at < 0 || held_owner[k][(size_t)at] != held_owner[k][i];
+            }
+            if (publish)
+                rim[k].push_back(RimRow{held_keys[k][i], g, held_owner[k][i], {0, 0, 0}});
+        }
+        if (any_joints)
+            for (size_t i = 0; i < s.held_ids.size(); ++i)
+                mw->slot_of[s.held_ids[i]] = -1;
+    }
+    std::vector<uint32_t> rim_count(n_local), rim_counts(w);
+    for (size_t k = 0; k < n_local; ++k) {
+        rim_count[k] = (uint32_t)rim[k].size();
+        send[k] = &rim_count[k];
+    }
+    MW_TRY(all_gather_host(mw, send, 4, gathered, st));
+    std::memcpy(rim_counts.data(), gathered.data(), (size_t)w * 4);
+    uint32_t cap_rim = 1;
+    for (uint32_t c : rim_counts)
+        cap_rim = std::max(cap_rim, c);
+    for (size_t k = 0; k < n_local; ++k) {
+        rim[k].resize(cap_rim, RimRow{0, UINT32_MAX, 0xFF, {0, 0, 0}});
+        send[k] = rim[k].data();
+    }
+    MW_TRY(all_gather_host(mw, send, (size_t)cap_rim * sizeof(RimRow), gathered, st));
+    if (trace.on)
+        std::fprintf(stderr, "[xpbd plan %llu] rim rows per rank: up to %u\n", (unsigned long long)mw->plans, cap_rim);
+    trace.lap("rims of the world");
+    // everybody's rim by body id: (key, owner, holder)
+    struct Known {
+        int64_t key;
+        uint8_t owner, holder;
+    };
+    std::unordered_map<uint32_t, Known> known;
+    if (st.ok()) {
+        size_t total = 0;
+        for (uint32_t c : rim_counts)
+            total += c;
+        known.reserve(total * 2 + 16);
+        for (uint32_t h = 0; h < w && st.ok(); ++h) {
+            const RimRow *rows = reinterpret_cast<const RimRow *>(gathered.data() + (size_t)h * cap_rim * sizeof(RimRow));
+            for (uint32_t i = 0; i < rim_counts[h]; ++i) {
+                if (rows[i].id >= n || rows[i].owner >= w || !known.emplace(rows[i].id, Known{rows[i].key, rows[i].owner, (uint8_t)h}).second) {
+                    st.keep(set_error(XPBD_E_INVALID, "xpbd_multi_world: body %u is held twice or out of range (rank %u)", rows[i].id, h));
+                    break;
+                }
+            }
+        }
+    }
+    std::vector<ShardPlan> plans(n_local);
+    for (size_t k = 0; k < n_local && st.ok(); ++k) {
+        Shard &s = mw->shards[k];
+        ShardPlan &pl = plans[k];
+        // what the shard will own: the held bodies that stay, and the published bodies of others that come to it
+        std::vector<std::pair<uint32_t, int64_t>> arriving;
+        std::vector<HaloPlanner::Foreign> foreign;
+        for (const auto &kv : known) {
+            if (kv.second.owner == s.rank) {
+                if (kv.second.holder != s.rank)
+                    arriving.emplace_back(kv.first, kv.second.key);
+            } else {
+                foreign.push_back(HaloPlanner::Foreign{kv.first, kv.second.key});
+            }
+        }
+        std::sort(arriving.begin(), arriving.end());
+        std::vector<int64_t> own_keys;
+        pl.own.reserve(s.held_ids.size() + arriving.size());
+        own_keys.reserve(s.held_ids.size() + arriving.size());
+        size_t ai = 0;
+        for (size_t i = 0; i <= s.held_ids.size(); ++i) {
+            const uint32_t g = i < s.held_ids.size() ? s.held_ids[i] : UINT32_MAX;
+            for (; ai < arriving.size() && arriving[ai].first < g; ++ai) {
+                pl.own.push_back(arriving[ai].first);
+                own_keys.push_back(arriving[ai].second);
+                pl.own_holder.push_back(known[arriving[ai].first].holder);
+            }
+            if (i < s.held_ids.size() && held_owner[k][i] == s.rank) {
+                pl.own.push_back(g);
+                own_keys.push_back(held_keys[k][i]);
+                pl.own_holder.push_back((uint8_t)s.rank);
+            }
+        }
+        if (pl.own.size() != owned_count[s.rank]) {
+            st.keep(set_error(XPBD_E_HIP, "xpbd_multi_world: rank %u is to own %u bodies but finds %zu (inconsistent plans)", s.rank, owned_count[s.rank],
+                              pl.own.size()));
+            break;
+        }
+        // joints that leave the rank: the other end was published by its holder (or is held here and goes elsewhere)
+        std::vector<HaloPlanner::CrossJoint> cross;
+        if (!mw->joints.empty()) {
+            for (uint32_t g : pl.own)
+                mw->slot_of[g] = 0; // (scratch: the bodies the shard will own)
+            for (uint32_t g : pl.own) {
+                for (uint32_t e = mw->joint_off[g]; e < mw->joint_off[g + 1] && st.ok(); ++e) {
+                    const xpbd_joint &j = mw->joints[mw->joint_adj[e]];
+                    const uint32_t other = j.body_a == g ? j.body_b : j.body_a;
+                    if (mw->slot_of[other] >= 0)
+                        continue;
+                    if (!known.count(other)) {
+                        st.keep(set_error(XPBD_E_HIP, "xpbd_multi_world: body %u (joint %u) is in nobody's rim (inconsistent plans)", other, mw->joint_adj[e]));
+                        break;
+                    }
+                    cross.push_back(HaloPlanner::CrossJoint{g, other});
+                }
+            }
+            for (uint32_t g : pl.own)
+                mw->slot_of[g] = -1;
+        }
+        if (!st.ok())
+            break;
+        HaloPlanner::plan_lists(pl.own, own_keys, foreign, cross, s.ghosts, s.boundary, &s.far);
+        pl.ghost_owner.resize(s.ghosts.size());
+        pl.ghost_holder.resize(s.ghosts.size());
+        for (size_t i = 0; i < s.ghosts.size(); ++i) {
+            const Known &kn = known[s.ghosts[i]];
+            pl.ghost_owner[i] = kn.owner, pl.ghost_holder[i] = kn.holder;
+        }
+        exports_of(s, held_owner[k], pl.exports);
+    }
+    trace.lap("halo plans (light)");
+    if (mw->check_plans) { // XPBD_MULTI_CHECK_PLANS=1: the same lists from the keys of the whole world (the full planner, same cuts)
+        std::vector<int64_t> keys;
+        std::vector<uint8_t> holder;
+        MW_TRY(gather_world_keys(mw, st, held_keys, max_held, keys, holder));
+        if (st.ok()) {
+            std::vector<uint8_t> owner(n);
+            for (uint32_t g = 0; g < n; ++g)
+                owner[g] = (uint8_t)owner_of(mw->cuts, slab_key(keys[g], mw->cut_axes), g);
+            HaloPlanner planner;
+            planner.n = n, planner.w = w, planner.keys = keys.data(), planner.owner = owner.data();
+            for (size_t k = 0; k < n_local && st.ok(); ++k) {
+                std::vector<uint32_t> own, ghosts, boundary;
+                std::vector<uint8_t> far;
+                planner.plan_rank(mw->shards[k].rank, mw->joints.data(), (uint32_t)mw->joints.size(), own, ghosts, boundary, &far);
+                const Shard &s = mw->shards[k];
+                if (own != plans[k].own || ghosts != s.ghosts || boundary != s.boundary || far != s.far)
+                    st.keep(set_error(XPBD_E_HIP, "xpbd_multi_world: the light plan of rank %u differs from the full planner's (own %zu / %zu, ghosts %zu / %zu, "
+                                                  "boundary %zu / %zu)", s.rank, plans[k].own.size(), own.size(), s.ghosts.size(), ghosts.size(),
+                                      s.boundary.size(), boundary.size()));
+            }
+        }
+        trace.lap("checked against the full planner");
+    }
+    MW_TRY(finish_plan(mw, st, plans, edge, trace));
+    mw->owner.clear(); // (rebuilt on demand: xpbd_multi_world_owners)
+    mw->owned_count.swap(owned_count);
+    mw->migrated = migrated;
+    ++mw->light_plans;
+    done = true;
+    return XPBD_OK;
+}
+
+// Builds ownership and halos from the bodies the shards own AT THE MOMENT (the first time: the index slices the caller handed
+// over, uploaded as they are) and re-packs every shard's local world.  Collective.
+int make_plan(xpbd_multi_world *mw, LocalStatus &st)
+{
+    const uint64_t t_plan = now_ns();
+    PlanTrace trace(mw->plans);
+    bool done = false;
+    if (mw->cuts_valid && mw->n_ranks > 1 && !(mw->flags & XPBD_MULTI_FULL_PLANS))
+        MW_TRY(make_plan_light(mw, st, trace, done));
+    if (!done)
+        MW_TRY(make_plan_full(mw, st, trace));
     mw->ns_plan += now_ns() - t_plan;
     return XPBD_OK;
 }
@@ -1582,7 +2001,7 @@ int xpbd_multi_world_create(xpbd_multi_world **out, const xpbd_multi_config *cfg
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: XPBD_TRANSPORT_RCCL needs comm_id (xpbd_comm_unique_id on one rank, handed to all)");
     if (!(cfg->contact_pad >= 0.0) || !(cfg->halo_margin > 0.0) || cfg->contact_pad > 1.0e6 || cfg->halo_margin > 1.0e6)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: contact_pad %g / halo_margin %g", cfg->contact_pad, cfg->halo_margin);
-    if (cfg->flags & ~(XPBD_MULTI_AUTO_REPLAN | XPBD_MULTI_PLAN_THROUGH_DEVICE | XPBD_MULTI_SERIAL_ENQUEUE))
+    if (cfg->flags & ~(XPBD_MULTI_AUTO_REPLAN | XPBD_MULTI_PLAN_THROUGH_DEVICE | XPBD_MULTI_SERIAL_ENQUEUE | XPBD_MULTI_FULL_PLANS))
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: unknown flags 0x%x", cfg->flags);
     if (cfg->narrowphase != XPBD_NARROWPHASE_SAT && cfg->narrowphase != XPBD_NARROWPHASE_GJK_EPA)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_create: unknown narrowphase %u", cfg->narrowphase);
@@ -1723,6 +2142,22 @@ int xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, cons
     mw->n_global = n_global, mw->first_global = first_global, mw->n_bodies = n_bodies;
     mw->joints.assign(joints, joints + n_joints);
     mw->planned = false;
+    mw->cuts_valid = false; // the first plan is a full one
+    mw->check_plans = std::getenv("XPBD_MULTI_CHECK_PLANS") != nullptr;
+    // the joints at every body (ascending joint index per body): the plans walk the joints of a rank's own bodies only
+    mw->joint_off.assign((size_t)n_global + 1, 0);
+    for (uint32_t j = 0; j < n_joints; ++j)
+        ++mw->joint_off[joints[j].body_a + 1], ++mw->joint_off[joints[j].body_b + 1];
+    for (uint32_t g = 0; g < n_global; ++g)
+        mw->joint_off[g + 1] += mw->joint_off[g];
+    mw->joint_adj.assign((size_t)2 * n_joints, 0);
+    {
+        std::vector<uint32_t> cursor(mw->joint_off.begin(), mw->joint_off.end() - 1);
+        for (uint32_t j = 0; j < n_joints; ++j) {
+            mw->joint_adj[cursor[joints[j].body_a]++] = j;
+            mw->joint_adj[cursor[joints[j].body_b]++] = j;
+        }
+    }
     // the largest bounding radius among the bodies handed over here (r_shape + |centroid - com|: a property of the bodies)
     mw->rmax_local = 0.0;
     for (uint32_t i = 0; i < n_bodies; ++i) {
@@ -1758,6 +2193,7 @@ int xpbd_multi_world_upload(xpbd_multi_world *mw, const xpbd_rigid *bodies, cons
     }
     mw->plans = 0;
     mw->rollbacks = 0;
+    mw->full_plans = mw->light_plans = 0;
     return make_plan(mw, st);
 }
 
@@ -1929,7 +2365,7 @@ int xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *m
     return XPBD_OK;
 }
 
-int xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10])
+int xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[12])
 {
     if (!mw || !out)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_plan_stats: NULL argument");
@@ -1940,6 +2376,7 @@ int xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10])
     }
     out[0] = mw->plans, out[1] = mw->rollbacks, out[2] = mw->migrated, out[3] = mw->owned_count.empty() ? 0 : lo, out[4] = hi;
     out[5] = mw->steps, out[6] = mw->ns_enqueue, out[7] = mw->ns_wait_broadphase, out[8] = mw->ns_wait_frame, out[9] = mw->ns_plan;
+    out[10] = mw->full_plans, out[11] = mw->light_plans;
     return XPBD_OK;
 }
 
@@ -1949,6 +2386,32 @@ int xpbd_multi_world_owners(xpbd_multi_world *mw, uint8_t *owner, uint32_t n_glo
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_owners: NULL argument");
     if (!mw->planned || n_global != mw->n_global)
         return set_error(XPBD_E_INVALID, "xpbd_multi_world_owners: n_global = %u but the world has %u bodies", n_global, mw->planned ? mw->n_global : 0);
+    if (mw->owner.size() != n_global) {
+        // a light plan does not know the owner of every body of the world: ask the ranks what they own (COLLECTIVE then)
+        LocalStatus st;
+        uint32_t cap = 1;
+        for (uint32_t c : mw->owned_count)
+            cap = std::max(cap, c);
+        const size_t n_local = mw->shards.size();
+        std::vector<std::vector<uint32_t>> ids(n_local);
+        std::vector<const void *> send(n_local);
+        for (size_t k = 0; k < n_local; ++k) {
+            ids[k].assign(cap, UINT32_MAX);
+            std::copy(mw->shards[k].held_ids.begin(), mw->shards[k].held_ids.end(), ids[k].begin());
+            send[k] = ids[k].data();
+        }
+        std::vector<uint8_t> gathered;
+        MW_TRY(all_gather_host(mw, send, (size_t)cap * 4, gathered, st));
+        std::vector<uint8_t> all(n_global, 0xFF);
+        for (uint32_t r = 0; r < mw->n_ranks; ++r)
+            for (uint32_t i = 0; i < mw->owned_count[r]; ++i) {
+                uint32_t g;
+                std::memcpy(&g, gathered.data() + ((size_t)r * cap + i) * 4, 4);
+                if (g < n_global)
+                    all[g] = (uint8_t)r;
+            }
+        mw->owner.swap(all);
+    }
     std::memcpy(owner, mw->owner.data(), n_global);
     return XPBD_OK;
 }
@@ -1974,7 +2437,8 @@ int xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n_
     if ((n_global && (!cell_keys || !owner)) || n_ranks == 0 || n_ranks > 64)
         return set_error(XPBD_E_INVALID, "xpbd_halo_partition: bad argument");
     std::vector<Cut> cuts;
-    compute_owners(cell_keys, n_global, n_ranks, owner, cuts);
+    int axes[3];
+    compute_owners(cell_keys, n_global, n_ranks, owner, cuts, axes);
     return XPBD_OK;
 }
 

@@ -208,7 +208,7 @@ extern "C" {
     pub fn xpbd_multi_world_download(mw: *mut XpbdMultiWorld, out: *mut XpbdRigid, n: u32) -> c_int;
     pub fn xpbd_multi_world_download_owned(mw: *mut XpbdMultiWorld, ids: *mut u32, out: *mut XpbdRigid, cap: u32, n_out: *mut u32) -> c_int;
     pub fn xpbd_multi_world_halo_stats(mw: *mut XpbdMultiWorld, out: *mut u64, max_displacement: *mut f64) -> c_int;
-    pub fn xpbd_multi_world_plan_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int;
+    pub fn xpbd_multi_world_plan_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int; // out: [u64; 12]
     pub fn xpbd_multi_world_owners(mw: *mut XpbdMultiWorld, owner: *mut u8, n_global: u32) -> c_int;
     pub fn xpbd_multi_world_contact_stats(mw: *mut XpbdMultiWorld, out: *mut u64) -> c_int;
     pub fn xpbd_halo_cell_key(centre: *const f64, cell_edge: f64) -> i64;

@@ -363,6 +363,9 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
                                            * local shards: one enqueueing thread per shard, see Threading above) */
 #define XPBD_MULTI_PLAN_THROUGH_DEVICE 2u /* diagnostics: the plan-time all-gathers go through the device transport even when
                                            * every rank lives in this process (the path a one-process-per-GPU run takes) */
+#define XPBD_MULTI_FULL_PLANS 8u          /* diagnostics: every re-plan re-cuts the shards from the cell keys of the WHOLE world
+                                           * (default: only the first plan and a re-plan that finds the shards a tenth of a share
+                                           * out of balance do; the others keep the cuts and exchange the rims of the shards only) */
 
 typedef struct xpbd_multi_config {
     uint32_t struct_size;   /* = sizeof(xpbd_multi_config) */
@@ -416,9 +419,10 @@ int  xpbd_multi_world_download_owned(xpbd_multi_world *mw, uint32_t *ids, xpbd_r
 int  xpbd_multi_world_halo_stats(xpbd_multi_world *mw, uint64_t out[6], double *max_displacement);
 /* out = {plans made, frames undone (halo violations), bodies that changed owner at the last plan, fewest / most bodies owned
  * by a rank, step calls, and the host time inside them in ns: enqueueing, waiting for the broadphases' pair counts, waiting
- * for the end of the frame; the host time of all plans (creation and re-plans) in ns}. */
-int  xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[10]);
-/* owner[g] = rank that owns body g as of the last plan (n_global entries). */
+ * for the end of the frame; the host time of all plans (creation and re-plans) in ns; how many of the plans were full ones
+ * (shards re-cut from the cell keys of the whole world) and how many light ones (cuts kept, only the rims exchanged)}. */
+int  xpbd_multi_world_plan_stats(xpbd_multi_world *mw, uint64_t out[12]);
+/* owner[g] = rank that owns body g as of the last plan (n_global entries).  COLLECTIVE when ranks live in other processes. */
 int  xpbd_multi_world_owners(xpbd_multi_world *mw, uint8_t *owner, uint32_t n_global);
 int  xpbd_multi_world_contact_stats(xpbd_multi_world *mw, uint64_t out[3]);             /* sums of xpbd_world_contact_stats */
 /* Diagnostics, host only (no device needed), exactly as the plans compute them.  The grid cell key of a bounding-sphere

@@ -230,6 +230,58 @@ def test_the_library_cuts_the_shards_whatever_the_callers_numbering(n_ranks):
     assert np.mean(results["shuffled"][1] == results["ordered"][1][perm]) > 0.97
 
 
+def test_light_plans_keep_the_cuts_and_equal_the_full_planner(monkeypatch):
+    """After the first plan a re-plan keeps the cuts and exchanges only the RIMS of the shards (bodies near a cut, bodies that
+    change owner, ends of joints that leave their holder).  With XPBD_MULTI_CHECK_PLANS the library also gathers the keys of
+    the whole world at every light plan and fails unless the full planner arrives at the same lists (owned, ghosts, boundary,
+    far) -- here for a pile with joints across the cuts, three shards, a re-plan every few frames; and the result equals the single
+    world and a world that makes full plans only (XPBD_MULTI_FULL_PLANS)."""
+    monkeypatch.setenv("XPBD_MULTI_CHECK_PLANS", "1")
+    kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 1200, 8, 30
+    bodies, sid = capi.scene_pile(kind, 5, n, 1.8, 3)
+    joints = chain_joints(capi, n, every=7)
+    centre = bodies[:, 31:34] + bodies[:, 28:31]
+    joints["distance"] = np.linalg.norm(centre[joints["body_b"]] - centre[joints["body_a"]], axis=1)
+    results = {}
+    for full in (False, True):
+        with capi.MultiWorld(3, devices=[0] * 3, transport=capi.TRANSPORT_LOCAL, halo_margin=1.0, auto_replan=True, full_plans=full,
+                             plan_through_device=not full) as mw:
+            mw.set_polytopes(capi.scene_polytopes(kind))
+            mw.upload(bodies, sid, 0, n, joints)
+            for f in range(frames):
+                if f % 3 == 1:
+                    mw.replan()
+                mw.step(DT, substeps)
+            stats = mw.plan_stats()
+            owners = mw.owners()
+            results[full] = mw.download()
+        assert stats["plans"] == stats["full_plans"] + stats["light_plans"] and stats["plans"] >= 11
+        assert (stats["light_plans"] == 0) if full else (stats["full_plans"] >= 1 and stats["light_plans"] >= 8)
+        assert np.bincount(owners, minlength=3).min() == stats["owned_min"] and np.bincount(owners, minlength=3).max() == stats["owned_max"]
+    one, _ = single(bodies, sid, kind, frames, substeps, joints)
+    assert bits_equal(results[False], one) and bits_equal(results[True], one)
+
+
+def test_a_drifting_world_gets_new_cuts_when_the_shards_are_out_of_balance():
+    """All bodies drift along the axis the shards are cut across: with the cuts kept, one shard would fill up and the other
+    empty.  A light plan that finds a shard a tenth of a share off balance gives way to a full plan (new cuts)."""
+    kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 256, 4, 90
+    bodies, sid = line_scene(capi, kind, n, 5, 1.3)
+    bodies[:, 22] += 12.0                                                 # 0.2 m per frame along the line: 18 m in 90 frames, 28 bodies across the cut
+    bodies[:, 10:13] = 0.0
+    with capi.MultiWorld(2, devices=[0, 0], transport=capi.TRANSPORT_LOCAL, halo_margin=0.5, auto_replan=True) as mw:
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.upload(bodies, sid, 0, n)
+        for _ in range(frames):
+            mw.step(DT, substeps)
+        stats = mw.plan_stats()
+        got = mw.download()
+    assert stats["light_plans"] >= 3 and stats["full_plans"] >= 2 and stats["rollbacks"] == 0
+    assert stats["owned_max"] - stats["owned_min"] <= n // 2 // 10 + 16    # never far out of balance
+    one, _ = single(bodies, sid, kind, frames, substeps)
+    assert bits_equal(got, one)
+
+
 def test_sharded_world_with_hinges_across_shards_and_the_depenetration_limit():
     """XPBD_JOINT_HINGE joints whose bodies live on different shards and xpbd_multi_world_set_max_depenetration_speed: the
     sharded world equals the single one bit for bit (the angular term reads the partner's rotation from its ghost)."""
