@@ -262,6 +262,35 @@ def test_light_plans_keep_the_cuts_and_equal_the_full_planner(monkeypatch):
     assert bits_equal(results[False], one) and bits_equal(results[True], one)
 
 
+def test_long_joints_between_bodies_far_from_any_cut(monkeypatch):
+    """Joints between bodies at opposite ends of the world: neither end is anywhere near a cut, both are mirrored by the other
+    end's owner all the same (a light plan learns about them because their holders publish the ends of joints that leave them).
+    Four shards, re-plans every other frame, checked against the full planner and the single world."""
+    monkeypatch.setenv("XPBD_MULTI_CHECK_PLANS", "1")
+    kind, n, substeps, frames = capi.SCENE_BOXES_DROP, 160, 6, 24
+    bodies, sid = line_scene(capi, kind, n, 17, 1.4)
+    order = np.argsort(bodies[:, 31], kind="stable")                      # along the line
+    ends = 24
+    joints = np.zeros(ends, dtype=capi.JOINT_DTYPE)
+    joints["body_a"], joints["body_b"] = order[:ends], order[::-1][:ends]
+    joints["anchor_a"], joints["anchor_b"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]
+    centre = bodies[:, 31:34] + bodies[:, 28:31]
+    joints["distance"] = np.linalg.norm(centre[joints["body_b"]] - centre[joints["body_a"]], axis=1)
+    with capi.MultiWorld(4, devices=[0] * 4, transport=capi.TRANSPORT_LOCAL, halo_margin=0.75, auto_replan=True, plan_through_device=True) as mw:
+        mw.set_polytopes(capi.scene_polytopes(kind))
+        mw.upload(bodies, sid, 0, n, joints)
+        halo = mw.halo_stats()
+        for f in range(frames):
+            if f % 2:
+                mw.replan()
+            mw.step(DT, substeps)
+        stats = mw.plan_stats()
+        got = mw.download()
+    assert halo["ghosts"] >= 2 * ends and stats["light_plans"] >= frames // 2
+    one, _ = single(bodies, sid, kind, frames, substeps, joints)
+    assert bits_equal(got, one)
+
+
 def test_a_drifting_world_gets_new_cuts_when_the_shards_are_out_of_balance():
     """All bodies drift along the axis the shards are cut across: with the cuts kept, one shard would fill up and the other
     empty.  A light plan that finds a shard a tenth of a share off balance gives way to a full plan (new cuts)."""
