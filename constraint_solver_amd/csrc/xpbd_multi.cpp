@@ -7,11 +7,13 @@
 // One xpbd_multi_world drives the LOCAL shards of a world of n_ranks shards -- all of them (a single process that owns
 // every GPU of the node: what a Rust host would do) or one each (one process per GPU, the ranks of a launcher).
 //
-// Ownership is the LIBRARY's: at every plan the bodies are binned into the cells of a uniform grid (edge = 2 * (largest
-// bounding radius + pad + halo_margin)), the cells are ordered by their spatial-hash cell key taken along the LONGEST axis of
-// the world first, and that sequence is cut into n_ranks runs of near-equal body count -- every rank owns a slab of space
-// across the world's longest axis, whatever order the caller numbered its
-// bodies in, and a re-plan re-balances the slabs as a pile migrates (bodies change owner then).  A shard is an ordinary
+// Ownership is the LIBRARY's: the bodies are binned into the cells of a uniform grid (edge = 2 * (largest bounding radius +
+// pad + halo_margin)), the cells are ordered by their spatial-hash cell key taken along the LONGEST axis of the world first,
+// and that sequence is cut into n_ranks runs of near-equal body count -- every rank owns a slab of space across the world's
+// longest axis, whatever order the caller numbered its bodies in.  The first plan cuts the slabs (a FULL plan: every rank
+// sees 16 bytes per body of the world); the re-plans keep the cuts, move the bodies that crossed one to their new owner and
+// exchange only the RIMS of the shards (LIGHT plans: make_plan_light), until a shard is a tenth of a share out of balance --
+// then the slabs are cut anew.  The bodies themselves stay on the devices through every plan.  A shard is an ordinary
 // xpbd_world in XPBD_MODE_CONTACTS holding its OWNED bodies plus GHOST copies of the remote bodies that can reach an owned
 // body before the next plan, in ascending GLOBAL id (the caller's numbering) -- so every neighbour list and every
 // floating-point sum has the order of the single-device run and the result is that run's, bit for bit.  Per substep:
@@ -19,7 +21,7 @@
 //     xGMI: ncclAllGather, all local shards in one group call) on a communication stream, overlapping the interior bodies ->
 //     the ghosts take their owners' state from the gathered buffer.
 // The plan (who owns, who mirrors whom) is built HERE, in C++, from the shards' own bodies plus a handful of small
-// all-gathers (cell keys, boundary lists, the records of migrating and boundary bodies); no rank holds the global scene.
+// all-gathers (cell keys or rims, boundary lists, the records of migrating and boundary bodies); no rank holds the global scene.
 // Every plan-time all-gather carries a status word per rank and so does the frame's last one, so a rank that fails locally
 // (out of memory, say) still takes part in the collectives and EVERY rank returns an error instead of the others hanging.
 //

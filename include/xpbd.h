@@ -323,10 +323,12 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
 /* ---------------------------------------------------------------------------
  * Multi-GPU world (EXTENSION): the caller is still World::integrate (src/world.rs:34-43), now over an N-body
  * world in XPBD_MODE_CONTACTS whose bodies are sharded over the GPUs of one node.  The caller numbers its bodies as it likes:
- * OWNERSHIP IS THE LIBRARY'S.  At every plan the bodies are binned into a uniform grid (cell edge = 2 * (largest bounding
- * radius + contact_pad + halo_margin)), the cells are ordered by spatial-hash cell key, longest axis of the world first, and
- * that sequence is cut into n_ranks runs of near-equal body count: every rank owns a slab of space across the world's
- * longest axis; a re-plan re-balances the slabs (bodies change owner as a pile migrates).  Bodies keep the caller's numbering everywhere in this interface.
+ * OWNERSHIP IS THE LIBRARY'S.  The bodies are binned into a uniform grid (cell edge = 2 * (largest bounding radius +
+ * contact_pad + halo_margin)), the cells are ordered by spatial-hash cell key, longest axis of the world first, and that
+ * sequence is cut into n_ranks runs of near-equal body count: every rank owns a slab of space across the world's longest
+ * axis.  A re-plan moves the bodies that crossed a cut to their new owner and cuts the slabs anew once a shard is a tenth of
+ * a share out of balance; the bodies stay on the devices through every plan.  Bodies keep the caller's numbering everywhere
+ * in this interface.
  * One xpbd_multi_world drives this process's LOCAL shards of the n_ranks shards of the world: all of them (one process owns
  * every GPU) or one each (one process per GPU).  Every shard steps its owned bodies plus ghost copies of the remote
  * bodies within reach, and after EVERY substep the boundary bodies' 13 dynamic doubles travel in ONE all-gather (RCCL over
@@ -335,8 +337,8 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
  * over all ranks, how much of its travel allowance any body has used since the plan (halo_margin next to a shard boundary,
  * halo_margin + half a cell edge for a body more than two cells away from every foreign one).  Beyond it a remote contact
  * may have been missed in that frame, so the frame is UNDONE (the state it started from is kept aside on the device) and
- * either run again after a re-plan (XPBD_MULTI_AUTO_REPLAN, which also re-plans pre-emptively when another frame like the last one would outrun the allowance) or
- * reported as XPBD_E_HALO with the frame's start state in place.  Result: bit-identical to one xpbd_world over the same bodies
+ * either run again after a re-plan (XPBD_MULTI_AUTO_REPLAN, which also re-plans pre-emptively when another frame like the
+ * last one would outrun the allowance) or reported as XPBD_E_HALO with the frame's start state in place.  Result: bit-identical to one xpbd_world over the same bodies
  * in the same order -- a state with possibly missed contacts never reaches the caller.
  *
  * Collective calls (create, upload, step, replan, download) must be made by every rank in the same order.  Failure model: a
