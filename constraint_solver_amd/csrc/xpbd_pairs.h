@@ -109,6 +109,7 @@ struct SatScratch {
     uint32_t *survivors;
     uint32_t calls;
     uint16_t *axis_cache;
+    bool cache_edge_axes; // the SAT kernels also leave separating EDGE axes in the cache (worth it in dense scenes only: the owner decides per frame)
 };
 
 // The contact pipeline answers "no contact" for pairs whose tight bounding spheres are disjoint (the diagnostic entry

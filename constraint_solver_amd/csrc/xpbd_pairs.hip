@@ -126,7 +126,7 @@ __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x 
 template <uint32_t L, class Lds, class M>
 __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const PolytopeTables &t, const double *__restrict__ frames,
                                          const uint32_t *__restrict__ pairs, uint32_t p, M *__restrict__ out, uint32_t lane,
-                                         uint16_t *__restrict__ axis_cache = nullptr, uint8_t *__restrict__ codes = nullptr)
+                                         uint16_t *__restrict__ axis_cache = nullptr, uint8_t *__restrict__ codes = nullptr, bool cache_edge_axes = false)
 {
     constexpr uint32_t H = L / 2;             // lanes per body in the two-sided stages
     constexpr uint32_t P = L < 16 ? L : 16;   // polygon capacity of the clipper: one vertex per lane, at most 16 (the
@@ -277,7 +277,7 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
             // the edge axis that separates the pair: the pre-test pass tries it first in the next substep -- if the gap is
             // worth it: a resting contact is "separated" by a few nanometres after one solve and touches again after the next
             // integration, and trying its axis first would only be paid for (XPBD_SAT_EDGE_CACHE_GAP, metres)
-            if (axis_cache && ebest > XPBD_SAT_EDGE_CACHE_GAP)
+            if (axis_cache && cache_edge_axes && ebest > XPBD_SAT_EDGE_CACHE_GAP)
                 axis_cache[p] = (uint16_t)(kAxisCacheEdge | eq);
         }
         return;
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
                                                                                    uint32_t *__restrict__ next_survivor_counts,
                                                                                    const uint32_t *__restrict__ survivors, uint32_t back_n,
                                                                                    ContactManifold *__restrict__ out, uint16_t *__restrict__ axis_cache,
-                                                                                   uint8_t *__restrict__ codes)
+                                                                                   uint8_t *__restrict__ codes, bool cache_edge_axes)
 {
     using Lds = typename SatLds<L, V>::Record;
     __shared__ Lds s_all[SatLds<L, V>::PW];
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(64, XPBD_SAT_MIN_WAVES_PER_SIMD) k_sat_survivo
         next_survivor_counts[threadIdx.x] = 0;
     if (k >= n)
         return;
-    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane, axis_cache, codes);
+    sat_pair<L>(s_all[group], b, t, frames, pairs, survivors[back_n ? back_n - 1u - k : k], out, lane, axis_cache, codes, cache_edge_axes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -765,18 +765,18 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,
-                               next, list->survivors, 0u, out, list->axis_cache, codes);
+                               next, list->survivors, 0u, out, list->axis_cache, codes, list->cache_edge_axes);
         });
         if (t.max_verts <= 16)
             hipLaunchKernelGGL((k_sat_survivors<XPBD_SAT_LS_LANES, 16>), dim3((n_pairs + 64 / XPBD_SAT_LS_LANES - 1) / (64 / XPBD_SAT_LS_LANES)), dim3(64), 0,
-                               stream, b, t, frames, pairs, count + 1, next, list->survivors, n_pairs, out, list->axis_cache, codes);
+                               stream, b, t, frames, pairs, count + 1, next, list->survivors, n_pairs, out, list->axis_cache, codes, list->cache_edge_axes);
         else
             hipLaunchKernelGGL((k_sat_survivors<32, kMaxV>), dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, count + 1, next,
-                               list->survivors, n_pairs, out, list->axis_cache, codes);
+                               list->survivors, n_pairs, out, list->axis_cache, codes, list->cache_edge_axes);
         for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs,
-                               count + 2, next, list->survivors + n_pairs, 0u, out, list->axis_cache, codes);
+                               count + 2, next, list->survivors + n_pairs, 0u, out, list->axis_cache, codes, list->cache_edge_axes);
         });
         return hipGetLastError();
     }
@@ -787,7 +787,7 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
             uint32_t *count = nullptr, *next = nullptr;
             (void)launch_pair_pretest(b, t, frames, pairs, n_pairs, codes, *list, &count, &next, stream, true);
             hipLaunchKernelGGL((k_sat_survivors<L, V>), grid, dim3(64), 0, stream, b, t, frames, pairs, count, next, list->survivors, 0u, out,
-                               list->axis_cache, codes);
+                               list->axis_cache, codes, list->cache_edge_axes);
         } else {
             hipLaunchKernelGGL((k_sat_pairs<L, V, true, ContactManifold>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, out, codes);
         }
