@@ -380,14 +380,14 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
             parts_j.append(j)
         joints = np.concatenate(parts_j)[: joints_n * n_ranks]
     if local_shards:
-        world = capi.MultiWorld(n_ranks, devices=[local_rank] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=0.5,
+        world = capi.MultiWorld(n_ranks, devices=[local_rank] * n_ranks, transport=capi.TRANSPORT_LOCAL, halo_margin=args.halo_margin,
                                 narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT, auto_replan=True)
         transport = "in-process peer copies (rehearsal: %d shards on one device)" % n_ranks
     else:
         cid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(cid, src=0)
         world = capi.MultiWorld(n_ranks, first_rank=rank, devices=[local_rank], transport=capi.TRANSPORT_RCCL, comm_id=cid[0],
-                                halo_margin=0.5, narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT,
+                                halo_margin=args.halo_margin, narrowphase=capi.NARROWPHASE_GJK_EPA if narrowphase == "gjk" else capi.NARROWPHASE_SAT,
                                 auto_replan=True)
         transport = "ncclAllGather, RCCL bound from %s" % capi.comm_library()
     world.set_polytopes(capi.scene_polytopes(kind))
@@ -414,7 +414,7 @@ def run_contacts_sharded(capi, np, torch, args, scene, kind, bodies, narrowphase
                                    "near-equal body counts, re-balanced at re-plans), owned + ghost bodies per rank; halo plan, end-of-frame "
                                    "halo-validity check (a violating frame is undone and re-run) and one all-gather per substep inside "
                                    "xpbd_multi_world_step (%s)" % transport,
-                       "halo": halo, "plan": world.plan_stats(), "neighbour_pairs_here": pairs, "touching_pairs_per_substep_here": touching / n_sub,
+                       "halo": halo, "halo_margin": args.halo_margin, "plan": world.plan_stats(), "neighbour_pairs_here": pairs, "touching_pairs_per_substep_here": touching / n_sub,
                        "manifold_points_per_substep_here": points / n_sub,
                        "extension": "not in the reference (parity unpinned; sharded == single device bit for bit)"},
             "roofline": None, "cpu_baseline": None,
@@ -442,7 +442,8 @@ def contacts_in_child_processes(args, rank):
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # rank 0 of the children hosts their store itself
     cmd = [sys.executable, os.path.abspath(__file__), "--contacts-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
-           "--warmup", str(args.warmup), "--substeps", str(args.substeps), "--seed", str(args.seed), "--backend", args.backend]
+           "--warmup", str(args.warmup), "--substeps", str(args.substeps), "--seed", str(args.seed), "--backend", args.backend,
+           "--halo-margin", str(args.halo_margin)]
     if args.single_device:
         cmd.append("--single-device")
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
@@ -480,6 +481,7 @@ def main():
                     help="skip the informational extra measurements (unfused roofline, HBM-resident size, PCIe-inclusive)")
     ap.add_argument("--no-contacts", action="store_true",
                     help="skip the `contacts` sub-results of the default run (box stacks with SAT contacts, mixed polyhedra on GJK/EPA)")
+    ap.add_argument("--halo-margin", type=float, default=1.0, help="sharded contact scenes: metres a body may travel between re-plans")
     ap.add_argument("--contacts-timeout", type=int, default=420,
                     help="N > 1: seconds after which the contacts sub-results are abandoned and the line is printed without them")
     ap.add_argument("--only", default="", help="profiling aid: run ONLY this part ('pinned', or a contacts sub-result name) "
