@@ -693,7 +693,8 @@ struct xpbd_multi_world {
     std::vector<uint32_t> joint_off, joint_adj; // [n_global + 1], [2 * joints]: the joints at every body (indices into `joints`, ascending)
     std::vector<Cut> cuts;            // the cuts of the last full plan, kept by the light plans between (cuts_valid)
     int cut_axes[3] = {0, 1, 2};      // ... over slab keys packed in this order of the axes
-    bool cuts_valid = false, check_plans = false;
+    bool cuts_valid = false, check_plans = false, plan_torn = false;
+    uint32_t balance_most = 0, balance_least = 0; // most / fewest bodies of a rank right after the last full plan
     uint64_t full_plans = 0, light_plans = 0;
     double last_displacement = 0.0; // the largest fraction of its travel allowance any body had used at the last check, times halo_margin
     Workers *workers = nullptr;     // one enqueueing thread per local shard (n_local > 1), started by the first step
@@ -923,6 +924,8 @@ struct PlanTrace {
 struct ShardPlan {
     std::vector<uint32_t> own, exports;
     std::vector<uint8_t> own_holder, ghost_owner, ghost_holder;
+    std::vector<uint32_t> ghosts, boundary; // (they replace Shard::ghosts / boundary / far only when the shard has been re-packed:
+    std::vector<uint8_t> far;               //  a plan that fails before that leaves the old plan as it was)
 };
 
 // The cell keys of the bodies every local shard holds, computed where the bodies are (8 bytes per body come back).
@@ -993,7 +996,7 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
     };
     std::vector<Counts> mine(n_local), counts(w);
     for (size_t k = 0; k < n_local; ++k) {
-        mine[k] = Counts{(uint32_t)mw->shards[k].boundary.size(), (uint32_t)plans[k].exports.size()};
+        mine[k] = Counts{(uint32_t)plans[k].boundary.size(), (uint32_t)plans[k].exports.size()};
         send[k] = &mine[k];
     }
     MW_TRY(all_gather_host(mw, send, sizeof(Counts), gathered, st));
@@ -1003,15 +1006,13 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
         cap = std::max(cap, counts[r].boundary);
         cap_exp = std::max(cap_exp, counts[r].exports);
     }
-    mw->capacity = cap;
     std::vector<uint32_t> lists((size_t)w * cap);
     {
         std::vector<std::vector<uint32_t>> pad_list(n_local);
         for (size_t k = 0; k < n_local; ++k) {
-            const Shard &s = mw->shards[k];
             pad_list[k].assign(cap, 0xFFFFFFFFu);
             if (st.ok())
-                std::copy(s.boundary.begin(), s.boundary.end(), pad_list[k].begin());
+                std::copy(plans[k].boundary.begin(), plans[k].boundary.end(), pad_list[k].begin());
             send[k] = pad_list[k].data();
         }
         MW_TRY(all_gather_host(mw, send, (size_t)cap * 4, gathered, st));
@@ -1052,7 +1053,7 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
 
     // 5. every shard's local world: owned + ghost bodies in ascending global id.  A body the shard owned before and still
     //    owns moves on the device; a body that arrives (a new owner, a ghost) comes from its holder's exported record.
-    const uint32_t rows = mw->rows_per_rank();
+    const uint32_t rows = cap; // (rows per rank of the per-substep all-gather from now on: mw->capacity, set when the plan has succeeded)
     auto exported = [&](const Shard &me, uint32_t g, uint32_t h) -> const double * {
         const uint32_t *lo = exp_lists.data() + (size_t)h * cap_exp, *hi = h < w ? lo + counts[h].exports : lo;
         const uint32_t *at = h < w ? std::lower_bound(lo, hi, g) : hi;
@@ -1068,16 +1069,16 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
         Shard &s = mw->shards[k];
         ShardPlan &pl = plans[k];
         MW_TRY(bind(s));
-        const uint32_t n_own = (uint32_t)pl.own.size(), n_ghost = (uint32_t)s.ghosts.size(), n_loc = n_own + n_ghost;
+        const uint32_t n_own = (uint32_t)pl.own.size(), n_ghost = (uint32_t)pl.ghosts.size(), n_loc = n_own + n_ghost;
         std::vector<int32_t> src(n_loc);
         std::vector<double> incoming;
-        std::vector<uint32_t> ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(s.boundary.size()), owned_slots(n_own);
+        std::vector<uint32_t> ghost_slots(n_ghost), ghost_rows(n_ghost), boundary_slots(pl.boundary.size()), owned_slots(n_own);
         std::vector<uint32_t> local_ids(n_loc);
         uint32_t slot = 0, oi = 0, gi = 0, n_in = 0;
         size_t old = 0; // walks the bodies owned so far (ascending, like pl.own)
         while (oi < n_own || gi < n_ghost) {
-            const bool take_own = gi >= n_ghost || (oi < n_own && pl.own[oi] < s.ghosts[gi]);
-            const uint32_t g = take_own ? pl.own[oi] : s.ghosts[gi];
+            const bool take_own = gi >= n_ghost || (oi < n_own && pl.own[oi] < pl.ghosts[gi]);
+            const uint32_t g = take_own ? pl.own[oi] : pl.ghosts[gi];
             local_ids[slot] = g;
             bool here = false;
             if (take_own && pl.own_holder[oi] == s.rank) {
@@ -1109,8 +1110,8 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
             }
             ++slot;
         }
-        for (size_t q = 0; q < s.boundary.size(); ++q)
-            boundary_slots[q] = owned_slots[std::lower_bound(pl.own.begin(), pl.own.end(), s.boundary[q]) - pl.own.begin()];
+        for (size_t q = 0; q < pl.boundary.size(); ++q)
+            boundary_slots[q] = owned_slots[std::lower_bound(pl.own.begin(), pl.own.end(), pl.boundary[q]) - pl.own.begin()];
         trace.lap("  source map of a shard");
         if (int rc = xpbd::repack_bodies(s.world, src.data(), n_loc, incoming.data(), n_in))
             return rc;
@@ -1159,7 +1160,7 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
         const double near_allow = mw->margin, far_allow = mw->margin + 0.5 * edge;
         const double near_scale = 1.0 / (near_allow * near_allow), far_scale = 1.0 / (far_allow * far_allow);
         for (uint32_t i = 0; i < n_own; ++i)
-            scale[i] = s.far[i] ? far_scale : near_scale;
+            scale[i] = pl.far[i] ? far_scale : near_scale;
         MW_TRY(upload_vector(s.disp_scale, scale, s.stream));
         MW_HIP_TRY(s.send.reserve((size_t)rows * kDyn * 8));
         MW_HIP_TRY(s.recv.reserve((size_t)w * rows * kDyn * 8));
@@ -1173,15 +1174,25 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
         s.owned_slots_h.swap(owned_slots);
         s.local_ids.swap(local_ids);
         s.held_ids.swap(pl.own); // from now on the shard holds what it owns
+        s.ghosts.swap(pl.ghosts);
+        s.boundary.swap(pl.boundary);
+        s.far.swap(pl.far);
         trace.lap("  index lists of a shard");
         return XPBD_OK;
     };
-    for (size_t k = 0; k < n_local && st.ok(); ++k)
+    for (size_t k = 0; k < n_local && st.ok(); ++k) {
         st.keep(build_shard(k));
+        if (!st.ok())
+            mw->plan_torn = true; // some shards re-packed, this one half-way: there is no plan to go back to (see make_plan)
+    }
     // all ranks leave the plan together: a last status-only exchange (a failed re-pack on one rank fails the plan everywhere)
     for (size_t k = 0; k < n_local; ++k)
         send[k] = nullptr;
-    MW_TRY(all_gather_host(mw, send, 0, gathered, st));
+    if (int rc = all_gather_host(mw, send, 0, gathered, st)) {
+        mw->plan_torn = true; // (a shard of some rank failed while being re-packed)
+        return rc;
+    }
+    mw->capacity = cap;
     mw->cell_edge = edge;
     mw->planned = true;
     mw->violated = false;
@@ -1191,16 +1202,16 @@ int finish_plan(xpbd_multi_world *mw, LocalStatus &st, std::vector<ShardPlan> &p
 }
 
 // What a shard holds and somebody else needs: bodies that change owner, and its (remaining) bodies that others mirror.
-// held_owner[i] = new owner of held body i; boundary = the shard's new boundary list (ascending).
-void exports_of(const Shard &s, const std::vector<uint8_t> &held_owner, std::vector<uint32_t> &exports)
+// held_owner[i] = new owner of held body i; boundary = the shard's NEW boundary list (ascending).
+void exports_of(const Shard &s, const std::vector<uint8_t> &held_owner, const std::vector<uint32_t> &boundary, std::vector<uint32_t> &exports)
 {
     exports.clear();
     size_t b = 0;
     for (size_t i = 0; i < s.held_ids.size(); ++i) {
         const uint32_t g = s.held_ids[i];
-        while (b < s.boundary.size() && s.boundary[b] < g)
+        while (b < boundary.size() && boundary[b] < g)
             ++b;
-        if (held_owner[i] != s.rank || (b < s.boundary.size() && s.boundary[b] == g))
+        if (held_owner[i] != s.rank || (b < boundary.size() && boundary[b] == g))
             exports.push_back(g);
     }
 }
@@ -1283,18 +1294,18 @@ int make_plan_full(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace)
         for (size_t k = 0; k < n_local; ++k) {
             Shard &s = mw->shards[k];
             ShardPlan &pl = plans[k];
-            planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), pl.own, s.ghosts, s.boundary, &s.far);
+            planner.plan_rank(s.rank, mw->joints.data(), (uint32_t)mw->joints.size(), pl.own, pl.ghosts, pl.boundary, &pl.far);
             pl.own_holder.resize(pl.own.size());
             for (size_t i = 0; i < pl.own.size(); ++i)
                 pl.own_holder[i] = holder[pl.own[i]];
-            pl.ghost_owner.resize(s.ghosts.size());
-            pl.ghost_holder.resize(s.ghosts.size());
-            for (size_t i = 0; i < s.ghosts.size(); ++i)
-                pl.ghost_owner[i] = owner[s.ghosts[i]], pl.ghost_holder[i] = holder[s.ghosts[i]];
+            pl.ghost_owner.resize(pl.ghosts.size());
+            pl.ghost_holder.resize(pl.ghosts.size());
+            for (size_t i = 0; i < pl.ghosts.size(); ++i)
+                pl.ghost_owner[i] = owner[pl.ghosts[i]], pl.ghost_holder[i] = holder[pl.ghosts[i]];
             held_owner.resize(s.held_ids.size());
             for (size_t i = 0; i < s.held_ids.size(); ++i)
                 held_owner[i] = owner[s.held_ids[i]];
-            exports_of(s, held_owner, pl.exports);
+            exports_of(s, held_owner, pl.boundary, pl.exports);
         }
     }
     trace.lap("halo plans");
@@ -1303,6 +1314,11 @@ int make_plan_full(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace)
     mw->owned_count.swap(owned_count);
     mw->migrated = migrated;
     mw->cuts_valid = true;
+    mw->balance_most = 0, mw->balance_least = UINT32_MAX;
+    for (uint32_t c : mw->owned_count) {
+        mw->balance_most = std::max(mw->balance_most, c);
+        mw->balance_least = std::min(mw->balance_least, c);
+    }
     ++mw->full_plans;
     return XPBD_OK;
 }
@@ -1360,7 +1376,8 @@ int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, boo
             most = std::max(most, c);
             least = std::min(least, c);
         }
-        if (most > share + share / 10 + 8 || least + share / 10 + 8 < share)
+        // (against what the last full plan achieved: cuts snap to cell boundaries, a world of few cells is never even)
+        if (most > mw->balance_most + share / 10 + 8 || least + share / 10 + 8 < mw->balance_least)
             return XPBD_OK; // (done stays false: the caller makes a full plan; every rank decides alike)
     }
     trace.lap("owners from the cuts");
@@ -1507,14 +1524,14 @@ int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, boo
         }
         if (!st.ok())
             break;
-        HaloPlanner::plan_lists(pl.own, own_keys, foreign, cross, s.ghosts, s.boundary, &s.far);
-        pl.ghost_owner.resize(s.ghosts.size());
-        pl.ghost_holder.resize(s.ghosts.size());
-        for (size_t i = 0; i < s.ghosts.size(); ++i) {
-            const Known &kn = known[s.ghosts[i]];
+        HaloPlanner::plan_lists(pl.own, own_keys, foreign, cross, pl.ghosts, pl.boundary, &pl.far);
+        pl.ghost_owner.resize(pl.ghosts.size());
+        pl.ghost_holder.resize(pl.ghosts.size());
+        for (size_t i = 0; i < pl.ghosts.size(); ++i) {
+            const Known &kn = known[pl.ghosts[i]];
             pl.ghost_owner[i] = kn.owner, pl.ghost_holder[i] = kn.holder;
         }
-        exports_of(s, held_owner[k], pl.exports);
+        exports_of(s, held_owner[k], pl.boundary, pl.exports);
     }
     trace.lap("halo plans (light)");
     if (mw->check_plans) { // XPBD_MULTI_CHECK_PLANS=1: the same lists from the keys of the whole world (the full planner, same cuts)
@@ -1531,11 +1548,11 @@ int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, boo
                 std::vector<uint32_t> own, ghosts, boundary;
                 std::vector<uint8_t> far;
                 planner.plan_rank(mw->shards[k].rank, mw->joints.data(), (uint32_t)mw->joints.size(), own, ghosts, boundary, &far);
-                const Shard &s = mw->shards[k];
-                if (own != plans[k].own || ghosts != s.ghosts || boundary != s.boundary || far != s.far)
+                const ShardPlan &pl = plans[k];
+                if (own != pl.own || ghosts != pl.ghosts || boundary != pl.boundary || far != pl.far)
                     st.keep(set_error(XPBD_E_HIP, "xpbd_multi_world: the light plan of rank %u differs from the full planner's (own %zu / %zu, ghosts %zu / %zu, "
-                                                  "boundary %zu / %zu)", s.rank, plans[k].own.size(), own.size(), s.ghosts.size(), ghosts.size(),
-                                      s.boundary.size(), boundary.size()));
+                                                  "boundary %zu / %zu)", mw->shards[k].rank, pl.own.size(), own.size(), pl.ghosts.size(), ghosts.size(),
+                                      pl.boundary.size(), boundary.size()));
             }
         }
         trace.lap("checked against the full planner");
@@ -1556,12 +1573,20 @@ int make_plan(xpbd_multi_world *mw, LocalStatus &st)
     const uint64_t t_plan = now_ns();
     PlanTrace trace(mw->plans);
     bool done = false;
+    int rc = XPBD_OK;
     if (mw->cuts_valid && mw->n_ranks > 1 && !(mw->flags & XPBD_MULTI_FULL_PLANS))
-        MW_TRY(make_plan_light(mw, st, trace, done));
-    if (!done)
-        MW_TRY(make_plan_full(mw, st, trace));
+        rc = make_plan_light(mw, st, trace, done);
+    if (rc == XPBD_OK && !done)
+        rc = make_plan_full(mw, st, trace);
     mw->ns_plan += now_ns() - t_plan;
-    return XPBD_OK;
+    if (rc != XPBD_OK && mw->plan_torn && !mw->broken) {
+        // A plan that fails BEFORE any shard is re-packed leaves the old plan and the state as they were (every rank returns
+        // the error); one that fails in the middle of the re-packing does not: the world cannot be used any more.
+        const std::string msg = xpbd_last_error();
+        mw->broken = true;
+        return set_error(rc, "%s -- the shards were being re-packed: destroy this xpbd_multi_world on every rank", msg.c_str());
+    }
+    return rc;
 }
 
 // The owned bodies' current state (ascending global id, like Shard::held_ids), for a download.

@@ -344,8 +344,10 @@ int  xpbd_world_max_displacement2(xpbd_world *w, const uint32_t *dev_indices, ui
  * Collective calls (create, upload, step, replan, download) must be made by every rank in the same order.  Failure model: a
  * rank that fails LOCALLY inside upload / replan / step / download (out of memory, a launch error) still takes part in the
  * call's collectives, each of which carries every rank's status, so EVERY rank returns an error from that call (the failing
- * rank its own, the others the same code with a message naming the rank) and a failed frame is undone everywhere.  If a
- * collective itself cannot be enqueued the communicator is aborted (ncclCommAbort: blocked peers return with an error) and
+ * rank its own, the others the same code with a message naming the rank) and a failed frame is undone everywhere.  A plan
+ * (upload, replan, the re-plans of a step) that fails before any shard has been re-packed leaves the previous plan and the
+ * state in place; one that fails while the shards are being re-packed leaves nothing to go back to: every later call on that
+ * world fails then, destroy it.  If a collective itself cannot be enqueued the communicator is aborted (ncclCommAbort: blocked peers return with an error) and
  * every later call on that world fails: destroy it.  Argument errors are returned before any collective: the ranks' hosts
  * pass consistent arguments.  A rank that never reaches xpbd_multi_world_create leaves its peers waiting inside RCCL's
  * bootstrap; only the host's launcher can detect that.
