@@ -389,11 +389,15 @@ __global__ void __launch_bounds__(64) k_gjk_pairs(BodyArrays b, PolytopeTables t
                                                   GjkResult *__restrict__ out, ContactManifold *__restrict__ manifolds,
                                                   uint32_t *__restrict__ hit_counts, uint32_t *__restrict__ hits, uint32_t segment_capacity,
                                                   unsigned long long *__restrict__ seeds, double *__restrict__ axis_cache,
-                                                  uint8_t *__restrict__ codes)
+                                                  uint8_t *__restrict__ codes, uint32_t *__restrict__ overflow_count)
 {
 #ifdef XPBD_GJK_TIMING
     unsigned long long tick_ = clock64();
 #endif
+    // (the overflow list of the expansion that follows starts empty: zeroed here instead of by a 4-byte fill of its own,
+    // which cost 5.8 us of stream time per substep)
+    if (overflow_count && blockIdx.x == 0 && threadIdx.x == 0)
+        *overflow_count = 0;
     constexpr uint32_t PW = 64 / L; // pairs per wave
     __shared__ GjkPairLds<V> s_all[PW];
     __shared__ StagedTables staged;
@@ -1196,6 +1200,8 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
     double *const axis = survivors ? scratch.axis_cache : nullptr;
     uint8_t *const codes = manifolds ? scratch.codes : nullptr;
     uint32_t segment_capacity = 0;
+    // the overflow list of the small-polytope expansion (below) and its counter, behind the hit list
+    uint32_t *const overflow_count = t.max_verts <= kSubVerts ? hits + n_pairs + kHitSegments * 64 + n_pairs : nullptr;
     auto launch = [&](auto lanes, auto pretest) {
         constexpr uint32_t L = decltype(lanes)::value, V = L == 32 ? kMaxV : 16;
         constexpr bool P = decltype(pretest)::value;
@@ -1203,10 +1209,10 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         segment_capacity = (grid.x + kHitSegments - 1) / kHitSegments * (64 / L); // what the workgroups of one segment can append
         if (staged)
             hipLaunchKernelGGL((k_gjk_pairs<L, V, P, true>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis, codes);
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis, codes, overflow_count);
         else
             hipLaunchKernelGGL((k_gjk_pairs<L, V, P, false>), grid, dim3(64), 0, stream, b, t, frames, pairs, n_pairs, survivors, survivor_count,
-                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis, codes);
+                               next_survivor_count, out, manifolds, count, hits, segment_capacity, seeds, axis, codes, overflow_count);
     };
     using std::integral_constant;
     // lanes per pair: XPBD_GJK_SMALL_LANES for shapes of at most 16 vertices (the simplex logic is replicated on every
@@ -1221,9 +1227,7 @@ hipError_t launch_gjk_epa_pairs(const BodyArrays &b, const PolytopeTables &t, co
         launch(integral_constant<uint32_t, 32>{}, std::false_type{});
     if (t.max_verts <= kSubVerts) {
         // small shapes: four hits per wave; the rare hit that outgrows the small polytope is redone by the wave-per-hit kernel
-        uint32_t *overflow = hits + n_pairs + kHitSegments * 64, *overflow_count = overflow + n_pairs;
-        if (hipError_t e = hipMemsetAsync(overflow_count, 0, 4, stream))
-            return e;
+        uint32_t *overflow = hits + n_pairs + kHitSegments * 64; // (overflow_count = overflow + n_pairs: zeroed by k_gjk_pairs above)
         // 8 lanes per hit where no face has more than four vertices (the manifold's clipper runs one polygon vertex per
         // lane, and a quadrilateral clipped against a quadrilateral has at most eight), 16 otherwise
         if (t.max_face_verts <= 4) {
