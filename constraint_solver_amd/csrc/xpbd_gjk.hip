@@ -26,6 +26,9 @@
 #include "xpbd_device.hpp"
 #include "xpbd_gjk.h"
 
+#ifndef XPBD_EPA_TIMING_STOP
+#define XPBD_EPA_TIMING_STOP 0
+#endif
 namespace xpbd {
 namespace {
 
@@ -577,25 +580,32 @@ __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const Sh
     static_assert(sizeof(s.vw) >= P * 3 * sizeof(double) && sizeof(s.fn) >= (P + kMaxFaceVerts) * 3 * sizeof(double),
                   "the clipper reuses the polytope's vertex rows and face normals");
     const Vec3 nrm = ld3(s.fn, best);
-    Vec3 pa{0.0, 0.0, 0.0}, pb{0.0, 0.0, 0.0};
     if (lane == 0 && axis) { // the penetration normal warm-starts the pair's next expansion (GjkScratch::axis_cache)
         axis[0] = nrm.x, axis[1] = nrm.y, axis[2] = nrm.z;
     }
-    if (lane == 0) {
-        const uint32_t i0 = face_vertex(s.fi[best], 0), i1 = face_vertex(s.fi[best], 1), i2 = face_vertex(s.fi[best], 2);
-        const Vec3 aw = ld3(s.vw, i0), proj = nrm * best_dist;
-        const Vec3 v0 = ld3(s.vw, i1) - aw, v1 = ld3(s.vw, i2) - aw, v2 = proj - aw;
+    // The witness points (barycentric coordinates of the origin's projection in the closest face: two divisions on one lane)
+    // are wanted by the diagnostic result and by the single-point contact only; a face contact -- nearly every hit of a
+    // stack or a settled pile -- never looks at them.  They must be taken before the clipper reuses the polytope's rows.
+    const uint32_t best_fi = s.fi[best];
+    const Vec3 w0 = ld3(s.vw, face_vertex(best_fi, 0)), w1 = ld3(s.vw, face_vertex(best_fi, 1)), w2 = ld3(s.vw, face_vertex(best_fi, 2));
+    const uint32_t ia0 = s.via[face_vertex(best_fi, 0)], ia1 = s.via[face_vertex(best_fi, 1)], ia2 = s.via[face_vertex(best_fi, 2)];
+    const uint32_t ib0 = s.vib[face_vertex(best_fi, 0)], ib1 = s.vib[face_vertex(best_fi, 1)], ib2 = s.vib[face_vertex(best_fi, 2)];
+    auto witness = [&](Vec3 &pa, Vec3 &pb) {
+        const Vec3 proj = nrm * best_dist;
+        const Vec3 v0 = w1 - w0, v1 = w2 - w0, v2 = proj - w0;
         const double d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
         const double denom = d00 * d11 - d01 * d01;
         const double bv = (d11 * d20 - d01 * d21) / denom, bw = (d00 * d21 - d01 * d20) / denom, bu = 1.0 - bv - bw;
-        pa = ld3(s.wa, s.via[i0]) * bu + ld3(s.wa, s.via[i1]) * bv + ld3(s.wa, s.via[i2]) * bw;
-        pb = ld3(s.wb, s.vib[i0]) * bu + ld3(s.wb, s.vib[i1]) * bv + ld3(s.wb, s.vib[i2]) * bw;
-        if (r) {
-            r->depth = best_dist;
-            r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
-            r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
-            r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
-        }
+        pa = ld3(s.wa, ia0) * bu + ld3(s.wa, ia1) * bv + ld3(s.wa, ia2) * bw;
+        pb = ld3(s.wb, ib0) * bu + ld3(s.wb, ib1) * bv + ld3(s.wb, ib2) * bw;
+    };
+    if (lane == 0 && r) {
+        Vec3 pa, pb;
+        witness(pa, pb);
+        r->depth = best_dist;
+        r->normal[0] = nrm.x, r->normal[1] = nrm.y, r->normal[2] = nrm.z;
+        r->point_a[0] = pa.x, r->point_a[1] = pa.y, r->point_a[2] = pa.z;
+        r->point_b[0] = pb.x, r->point_b[1] = pb.y, r->point_b[2] = pb.z;
     }
     if (!mf) // group-uniform
         return;
@@ -633,6 +643,8 @@ __device__ __forceinline__ void epa_emit(S &s, const PolytopeTables &t, const Sh
     if (n_out) {
         *code = (uint8_t)(n_out | (ref << kPairCodeFeatureShift));
     } else {
+        Vec3 pa, pb;
+        witness(pa, pb);
         *code = (uint8_t)(1u | (2u << kPairCodeFeatureShift)); // one point, reference body A, incident body B
         set_single_contact(*mf, pb, pa);                      // pb on the incident body B, pa on the reference body A
     }
@@ -979,6 +991,10 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         }
     }
     __syncthreads();
+#if XPBD_EPA_TIMING_STOP == 1 // (diagnostic builds: where does the time of a hit go?  wrong results)
+    finish(2);
+    return true;
+#endif
 
     for (uint32_t it = 0; it < kMaxEpaIters; ++it) {
         epa_iters = it + 1;
@@ -1088,6 +1104,17 @@ __device__ __forceinline__ bool epa_pair_sub(EpaSubLds &s, const BodyArrays &b, 
         }
     }
 
+#if XPBD_EPA_TIMING_STOP == 2
+    {
+        double bd;
+        const uint32_t bf = closest(nf, &bd);
+        const Vec3 nrm = ld3(s.fn, bf);
+        if (lane == 0 && axis_cache) // (keep the warm start of the next substep, as epa_emit would)
+            axis_cache[3 * (size_t)p] = nrm.x, axis_cache[3 * (size_t)p + 1] = nrm.y, axis_cache[3 * (size_t)p + 2] = nrm.z;
+    }
+    finish(2);
+    return true;
+#endif
     double best_dist;
     const uint32_t best = closest(nf, &best_dist);
     epa_emit<L>(s, t, da, db, fa, fb, best, best_dist, r, mf, code, axis_cache ? axis_cache + 3 * (size_t)p : nullptr, lane);

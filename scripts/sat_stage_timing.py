@@ -20,19 +20,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--save")
     ap.add_argument("--load")
-    ap.add_argument("--scene", default="boxes", choices=["boxes", "mixed"])
+    ap.add_argument("--scene", default="boxes", choices=["boxes", "mixed", "stacks"])
+    ap.add_argument("--narrowphase", default="sat", choices=["sat", "gjk"])
     ap.add_argument("--bodies", type=int, default=262144)
     ap.add_argument("--frames", type=int, default=3)
     args = ap.parse_args()
-    kind = capi.SCENE_BOXES_DROP if args.scene == "boxes" else capi.SCENE_MIXED_DROP
+    kind = {"boxes": capi.SCENE_BOXES_DROP, "mixed": capi.SCENE_MIXED_DROP, "stacks": capi.SCENE_BOX_STACKS}[args.scene]
     with capi.World(mode=capi.MODE_CONTACTS) as w:
         w.set_polytopes(capi.scene_polytopes(kind))
+        w.set_narrowphase(capi.NARROWPHASE_GJK_EPA if args.narrowphase == "gjk" else capi.NARROWPHASE_SAT)
         if args.scene == "mixed":
             w.set_max_depenetration_speed(3.0)
         if args.save:
-            bodies, sid = capi.scene_pile(kind, 1, args.bodies, 1.8 if args.scene == "boxes" else 1.4, 4)
+            if args.scene == "stacks":
+                bodies, sid = capi.scene_generate(kind, 1, args.bodies, grid_w=capi.default_grid_width(max(args.bodies // 16, 1)))
+            else:
+                bodies, sid = capi.scene_pile(kind, 1, args.bodies, 1.8 if args.scene == "boxes" else 1.4, 4)
             w.upload(bodies, sid)
-            for _ in range(180 if args.scene == "boxes" else 240):
+            for _ in range({"boxes": 180, "mixed": 240, "stacks": 30}[args.scene]):
                 w.step(1 / 60, 20)
             np.savez(args.save, bodies=w.download(), sid=sid)
             return
