@@ -74,16 +74,24 @@ def contacts_case(rng, max_bodies=2500):
         joints = np.zeros(k, dtype=capi.JOINT_DTYPE)
         joints["body_a"], joints["body_b"] = a, a + 1
         joints["anchor_a"], joints["anchor_b"], joints["distance"] = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], float(rng.uniform(0.5, 2.0))
+        if rng.random() < 0.5:                                         # round 3: some of them hinges (ball joint + axis alignment)
+            hinge = r2.random(k) < 0.5
+            axes = r2.normal(size=(2, k, 3))
+            axes /= np.linalg.norm(axes, axis=2, keepdims=True)
+            joints["kind"][hinge], joints["distance"][hinge] = capi.JOINT_HINGE, 0.0
+            joints["axis_a"][hinge], joints["axis_b"][hinge] = axes[0][hinge], axes[1][hinge]
+    limit = float(rng.choice([0.0, 0.0, 1.0, 3.0]))                      # round 3: xpbd_world_set_max_depenetration_speed
     polys = ob.polytopes_array(POLY[kind])
     t0 = time.time()
     want = bodies
     for _ in range(frames):
-        want = ob.contacts_step_joints(want, sid, polys, joints, 1 / 60, substeps, pad, narrowphase=narrowphase)
+        want = ob.contacts_step_joints(want, sid, polys, joints, 1 / 60, substeps, pad, narrowphase=narrowphase, max_depenetration_speed=limit)
     with capi.World(mode=capi.MODE_CONTACTS) as w:
         w.set_polytopes(capi.scene_polytopes(kind))
         w.set_contact_pad(pad)
         w.set_narrowphase(narrowphase)
         w.set_sat_schedule(schedule)
+        w.set_max_depenetration_speed(limit)
         w.upload(bodies, sid)
         if len(joints):
             w.set_joints(joints)
@@ -91,7 +99,8 @@ def contacts_case(rng, max_bodies=2500):
             w.step(1 / 60, substeps)
         got = w.download()
         _, touching, _ = w.contact_stats()
+    hinges = int((joints["kind"] == capi.JOINT_HINGE).sum()) if len(joints) else 0
     return bits_or_nan_equal(got, want), ("kind %d n %4d substeps %2d frames %d narrowphase %d schedule %d pad %.2f width %5.2f "
-                                          "joints %3d touching %d (%.1f s)"
-                                          % (kind, n, substeps, frames, narrowphase, schedule, pad, width, len(joints), touching,
+                                          "joints %3d (%d hinges) limit %.0f touching %d (%.1f s)"
+                                          % (kind, n, substeps, frames, narrowphase, schedule, pad, width, len(joints), hinges, limit, touching,
                                              time.time() - t0))
