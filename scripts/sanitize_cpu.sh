@@ -22,3 +22,11 @@ export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
   python -m pytest -q -p no:cacheprovider tests/test_oracle_kat.py tests/test_pairs_oracle.py tests/test_gjk_oracle.py \
   tests/test_joints_oracle.py tests/test_golden_oracle.py tests/test_host_mirror.py
+# ... and the host-only planner of the multi-GPU world (partition, halo plans: csrc/xpbd_multi.cpp compiled by g++ with the
+# sanitizers and linked with the other objects of the HIP library) through its CPU tests.
+g++ $SAN -std=c++17 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c constraint_solver_amd/csrc/xpbd_multi.cpp -o "$TMP/multi_san.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$TMP/libxpbd_hip_san.so" \
+    $(ls constraint_solver_amd/lib/obj/*.o | grep -v xpbd_multi) "$TMP/multi_san.o" -ldl -lpthread
+XPBD_HIP_LIB="$TMP/libxpbd_hip_san.so" LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
+  python -m pytest -q -p no:cacheprovider tests/test_halo_plan_native.py tests/test_abi.py
+
