@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "xpbd_comm_unique_id", "xpbd_comm_library", "xpbd_multi_config_default", "xpbd_multi_world_create", "xpbd_multi_world_destroy",
     "xpbd_multi_world_set_polytopes", "xpbd_multi_world_upload", "xpbd_multi_world_step", "xpbd_multi_world_replan",
     "xpbd_multi_world_synchronize", "xpbd_multi_world_download", "xpbd_multi_world_halo_stats", "xpbd_multi_world_contact_stats",
-    "xpbd_halo_cell_key", "xpbd_halo_plan", "xpbd_halo_plan_far", "xpbd_halo_partition", "xpbd_halo_plan_owned",
+    "xpbd_halo_cell_key", "xpbd_halo_plan", "xpbd_halo_plan_far", "xpbd_halo_partition", "xpbd_halo_plan_owned", "xpbd_halo_plan_light",
     "xpbd_multi_world_download_owned", "xpbd_multi_world_plan_stats", "xpbd_multi_world_owners",
     "xpbd_world_history_push", "xpbd_world_history_restore", "xpbd_world_history_truncate", "xpbd_world_history_length",
 ]
@@ -596,6 +596,25 @@ def halo_plan_owned(cell_keys, owner, n_ranks, rank, joints=None, with_far=False
     if with_far:
         return ghosts[: ng.value].copy(), boundary[: nb.value].copy(), far[: int((own == rank).sum())].copy()
     return ghosts[: ng.value].copy(), boundary[: nb.value].copy()
+
+
+def halo_plan_light(keys_at_cut, cell_keys, n_ranks, rank, joints=None):
+    """(owner of every body now, own ids, ghost ids, boundary ids, far flags) of one rank's LIGHT plan (host only): cuts from
+    `keys_at_cut`, owners from `cell_keys` and those cuts, halos from the rank's own bodies and everybody's rims."""
+    k0 = np.ascontiguousarray(keys_at_cut, dtype=np.int64)
+    k1 = np.ascontiguousarray(cell_keys, dtype=np.int64)
+    n = len(k1)
+    j = np.zeros(0, dtype=JOINT_DTYPE) if joints is None else np.ascontiguousarray(joints, dtype=JOINT_DTYPE)
+    owner = np.zeros(n, dtype=np.uint8)
+    own, ghosts, boundary = (np.zeros(n, dtype=np.uint32) for _ in range(3))
+    far = np.zeros(n, dtype=np.uint8)
+    no, ng, nb = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    L = hip_lib()
+    L.xpbd_halo_plan_light.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, _u32p, _u32p,
+                                       _u32p, _u32p, _u32p, _u32p, C.c_void_p, C.c_uint32]
+    _check(L.xpbd_halo_plan_light(k0.ctypes.data, k1.ctypes.data, n, n_ranks, rank, j.ctypes.data if j.size else None, j.size, owner.ctypes.data,
+                                  _u32(own), C.byref(no), _u32(ghosts), C.byref(ng), _u32(boundary), C.byref(nb), far.ctypes.data, n))
+    return owner, own[: no.value].copy(), ghosts[: ng.value].copy(), boundary[: nb.value].copy(), far[: no.value].copy()
 
 
 def halo_plan_far(cell_keys, n_ranks, rank):

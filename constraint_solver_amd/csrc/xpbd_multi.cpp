@@ -1323,6 +1323,134 @@ int make_plan_full(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace)
     return XPBD_OK;
 }
 
+// ---- the pieces of a light plan that are pure host logic (also behind the diagnostic xpbd_halo_plan_light) -----------------
+struct RimRow { // what a holder publishes of a body: its cell key, its id, its new owner
+    int64_t key;
+    uint32_t id;
+    uint8_t owner, pad[3];
+};
+struct Known { // ... and what everybody then knows of it
+    int64_t key;
+    uint8_t owner, holder;
+};
+using KnownMap = std::unordered_map<uint32_t, Known>;
+struct JointIndex { // the joints of the world and, per body, the joints it is an end of (ascending joint index)
+    const xpbd_joint *joints;
+    const uint32_t *off, *adj;
+    bool any;
+};
+
+std::vector<int64_t> cut_layers_of(const std::vector<Cut> &cuts)
+{
+    std::vector<int64_t> layers;
+    for (size_t r = 1; r < cuts.size(); ++r)
+        if (cuts[r].key != INT64_MAX)
+            layers.push_back((cuts[r].key >> 42) - kCellBias);
+    std::sort(layers.begin(), layers.end());
+    layers.erase(std::unique(layers.begin(), layers.end()), layers.end());
+    return layers;
+}
+
+// The RIM a holder publishes: its bodies within two layers of a cut (no body further from every cut can lie within two cells
+// of a foreign cell: a rank's bodies and a foreign body near them sit on opposite sides of a cut layer), the bodies that
+// change owner, and the ends of joints that leave the shard (the other end is held elsewhere, or the two ends get different
+// owners).  slot_of: [n_global] scratch, -1 everywhere on entry and on return.
+void rim_rows_of(uint32_t rank, const std::vector<uint32_t> &held_ids, const std::vector<int64_t> &held_keys, const std::vector<uint8_t> &held_owner,
+                 const std::vector<int64_t> &held_slab, const std::vector<int64_t> &cut_layers, const JointIndex &ji, std::vector<int32_t> &slot_of,
+                 std::vector<RimRow> &rows)
+{
+    auto near_a_cut = [&](int64_t slab) {
+        const int64_t layer = (slab >> 42) - kCellBias;
+        const auto at = std::lower_bound(cut_layers.begin(), cut_layers.end(), layer - 2);
+        return at != cut_layers.end() && *at <= layer + 2;
+    };
+    if (ji.any) // (scratch: where in the held lists a body of this shard sits)
+        for (size_t i = 0; i < held_ids.size(); ++i)
+            slot_of[held_ids[i]] = (int32_t)i;
+    for (size_t i = 0; i < held_ids.size(); ++i) {
+        const uint32_t g = held_ids[i];
+        bool publish = held_owner[i] != rank || near_a_cut(held_slab[i]);
+        for (uint32_t e = ji.any ? ji.off[g] : 0u; ji.any && e < ji.off[g + 1] && !publish; ++e) {
+            const xpbd_joint &j = ji.joints[ji.adj[e]];
+            const int32_t at = slot_of[j.body_a == g ? j.body_b : j.body_a];
+            // the other end lives elsewhere now, or will: this end's owner (or mirror) must learn about both
+            publish = at < 0 || held_owner[(size_t)at] != held_owner[i];
+        }
+        if (publish)
+            rows.push_back(RimRow{held_keys[i], g, held_owner[i], {0, 0, 0}});
+    }
+    if (ji.any)
+        for (size_t i = 0; i < held_ids.size(); ++i)
+            slot_of[held_ids[i]] = -1;
+}
+
+// One rank's new plan from the bodies it holds and everybody's rims: what it will own (the held bodies that stay and the
+// published bodies that come to it), its ghosts / boundary / far lists, who owns and holds the ghosts.
+int light_rank_plan(uint32_t rank, const std::vector<uint32_t> &held_ids, const std::vector<int64_t> &held_keys, const std::vector<uint8_t> &held_owner,
+                    KnownMap &known, const JointIndex &ji, std::vector<int32_t> &slot_of, ShardPlan &pl)
+{
+    std::vector<std::pair<uint32_t, int64_t>> arriving;
+    std::vector<HaloPlanner::Foreign> foreign;
+    for (const auto &kv : known) {
+        if (kv.second.owner == rank) {
+            if (kv.second.holder != rank)
+                arriving.emplace_back(kv.first, kv.second.key);
+        } else {
+            foreign.push_back(HaloPlanner::Foreign{kv.first, kv.second.key});
+        }
+    }
+    std::sort(arriving.begin(), arriving.end());
+    std::vector<int64_t> own_keys;
+    pl.own.reserve(held_ids.size() + arriving.size());
+    own_keys.reserve(held_ids.size() + arriving.size());
+    size_t ai = 0;
+    for (size_t i = 0; i <= held_ids.size(); ++i) {
+        const uint32_t g = i < held_ids.size() ? held_ids[i] : UINT32_MAX;
+        for (; ai < arriving.size() && arriving[ai].first < g; ++ai) {
+            pl.own.push_back(arriving[ai].first);
+            own_keys.push_back(arriving[ai].second);
+            pl.own_holder.push_back(known[arriving[ai].first].holder);
+        }
+        if (i < held_ids.size() && held_owner[i] == rank) {
+            pl.own.push_back(g);
+            own_keys.push_back(held_keys[i]);
+            pl.own_holder.push_back((uint8_t)rank);
+        }
+    }
+    // joints that leave the rank: the other end was published by its holder (or is held here and goes elsewhere)
+    std::vector<HaloPlanner::CrossJoint> cross;
+    int rc = XPBD_OK;
+    if (ji.any) {
+        for (uint32_t g : pl.own)
+            slot_of[g] = 0; // (scratch: the bodies the shard will own)
+        for (uint32_t g : pl.own) {
+            for (uint32_t e = ji.off[g]; e < ji.off[g + 1] && rc == XPBD_OK; ++e) {
+                const xpbd_joint &j = ji.joints[ji.adj[e]];
+                const uint32_t other = j.body_a == g ? j.body_b : j.body_a;
+                if (slot_of[other] >= 0)
+                    continue;
+                if (!known.count(other)) {
+                    rc = set_error(XPBD_E_HIP, "xpbd_multi_world: body %u (joint %u) is in nobody's rim (inconsistent plans)", other, ji.adj[e]);
+                    break;
+                }
+                cross.push_back(HaloPlanner::CrossJoint{g, other});
+            }
+        }
+        for (uint32_t g : pl.own)
+            slot_of[g] = -1;
+    }
+    if (rc != XPBD_OK)
+        return rc;
+    HaloPlanner::plan_lists(pl.own, own_keys, foreign, cross, pl.ghosts, pl.boundary, &pl.far);
+    pl.ghost_owner.resize(pl.ghosts.size());
+    pl.ghost_holder.resize(pl.ghosts.size());
+    for (size_t i = 0; i < pl.ghosts.size(); ++i) {
+        const Known &kn = known[pl.ghosts[i]];
+        pl.ghost_owner[i] = kn.owner, pl.ghost_holder[i] = kn.holder;
+    }
+    return XPBD_OK;
+}
+
 // A LIGHT plan: the cuts stay where the last full plan put them, so a body's owner follows from its own cell key, and what a
 // rank must know of the others is the RIM -- the bodies within two layers of a cut (nobody else can lie within two cells of a
 // foreign cell), the bodies that change owner, and the ends of joints that leave their holder.  Host work and traffic are
@@ -1381,49 +1509,14 @@ int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, boo
             return XPBD_OK; // (done stays false: the caller makes a full plan; every rank decides alike)
     }
     trace.lap("owners from the cuts");
-    // the rim: (key, id, new owner) of the held bodies near a cut, changing owner, or at the end of a joint that leaves the shard
-    // (the other end is held elsewhere, or the two ends get different owners)
-    struct RimRow {
-        int64_t key;
-        uint32_t id;
-        uint8_t owner, pad[3];
-    };
-    std::vector<int64_t> cut_layers;
-    for (uint32_t r = 1; r < w; ++r)
-        if (mw->cuts[r].key != INT64_MAX)
-            cut_layers.push_back((mw->cuts[r].key >> 42) - kCellBias);
-    std::sort(cut_layers.begin(), cut_layers.end());
-    cut_layers.erase(std::unique(cut_layers.begin(), cut_layers.end()), cut_layers.end());
-    auto near_a_cut = [&](int64_t slab) {
-        const int64_t layer = (slab >> 42) - kCellBias;
-        const auto at = std::lower_bound(cut_layers.begin(), cut_layers.end(), layer - 2);
-        return at != cut_layers.end() && *at <= layer + 2;
-    };
+    // the rims: (key, id, new owner) of the held bodies near a cut, changing owner, or at the end of a joint that leaves the shard
+    const std::vector<int64_t> cut_layers = cut_layers_of(mw->cuts);
+    const JointIndex ji{mw->joints.data(), mw->joint_off.data(), mw->joint_adj.data(), !mw->joints.empty()};
     std::vector<std::vector<RimRow>> rim(n_local);
     if (mw->slot_of.size() != n)
         mw->slot_of.assign(n, -1);
-    for (size_t k = 0; k < n_local && st.ok(); ++k) {
-        const Shard &s = mw->shards[k];
-        const bool any_joints = !mw->joints.empty();
-        if (any_joints) // (scratch: where in the held lists a body of this shard sits)
-            for (size_t i = 0; i < s.held_ids.size(); ++i)
-                mw->slot_of[s.held_ids[i]] = (int32_t)i;
-        for (size_t i = 0; i < s.held_ids.size(); ++i) {
-            const uint32_t g = s.held_ids[i];
-            bool publish = held_owner[k][i] != s.rank || near_a_cut(held_slab[k][i]);
-            for (uint32_t e = mw->joint_off[g]; e < mw->joint_off[g + 1] && !publish; ++e) {
-                const xpbd_joint &j = mw->joints[mw->joint_adj[e]];
-                const int32_t at = mw->slot_of[j.body_a == g ? j.body_b : j.body_a];
-                // the other end lives elsewhere now, or will: this end's owner (or mirror) must learn about both
-                publish = at < 0 || held_owner[k][(size_t)at] != held_owner[k][i];
-            }
-            if (publish)
-                rim[k].push_back(RimRow{held_keys[k][i], g, held_owner[k][i], {0, 0, 0}});
-        }
-        if (any_joints)
-            for (size_t i = 0; i < s.held_ids.size(); ++i)
-                mw->slot_of[s.held_ids[i]] = -1;
-    }
+    for (size_t k = 0; k < n_local && st.ok(); ++k)
+        rim_rows_of(mw->shards[k].rank, mw->shards[k].held_ids, held_keys[k], held_owner[k], held_slab[k], cut_layers, ji, mw->slot_of, rim[k]);
     std::vector<uint32_t> rim_count(n_local), rim_counts(w);
     for (size_t k = 0; k < n_local; ++k) {
         rim_count[k] = (uint32_t)rim[k].size();
@@ -1443,11 +1536,7 @@ int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, boo
         std::fprintf(stderr, "[xpbd plan %llu] rim rows per rank: up to %u\n", (unsigned long long)mw->plans, cap_rim);
     trace.lap("rims of the world");
     // everybody's rim by body id: (key, owner, holder)
-    struct Known {
-        int64_t key;
-        uint8_t owner, holder;
-    };
-    std::unordered_map<uint32_t, Known> known;
+    KnownMap known;
     if (st.ok()) {
         size_t total = 0;
         for (uint32_t c : rim_counts)
@@ -1467,69 +1556,13 @@ int make_plan_light(xpbd_multi_world *mw, LocalStatus &st, PlanTrace &trace, boo
     for (size_t k = 0; k < n_local && st.ok(); ++k) {
         Shard &s = mw->shards[k];
         ShardPlan &pl = plans[k];
-        // what the shard will own: the held bodies that stay, and the published bodies of others that come to it
-        std::vector<std::pair<uint32_t, int64_t>> arriving;
-        std::vector<HaloPlanner::Foreign> foreign;
-        for (const auto &kv : known) {
-            if (kv.second.owner == s.rank) {
-                if (kv.second.holder != s.rank)
-                    arriving.emplace_back(kv.first, kv.second.key);
-            } else {
-                foreign.push_back(HaloPlanner::Foreign{kv.first, kv.second.key});
-            }
-        }
-        std::sort(arriving.begin(), arriving.end());
-        std::vector<int64_t> own_keys;
-        pl.own.reserve(s.held_ids.size() + arriving.size());
-        own_keys.reserve(s.held_ids.size() + arriving.size());
-        size_t ai = 0;
-        for (size_t i = 0; i <= s.held_ids.size(); ++i) {
-            const uint32_t g = i < s.held_ids.size() ? s.held_ids[i] : UINT32_MAX;
-            for (; ai < arriving.size() && arriving[ai].first < g; ++ai) {
-                pl.own.push_back(arriving[ai].first);
-                own_keys.push_back(arriving[ai].second);
-                pl.own_holder.push_back(known[arriving[ai].first].holder);
-            }
-            if (i < s.held_ids.size() && held_owner[k][i] == s.rank) {
-                pl.own.push_back(g);
-                own_keys.push_back(held_keys[k][i]);
-                pl.own_holder.push_back((uint8_t)s.rank);
-            }
-        }
+        st.keep(light_rank_plan(s.rank, s.held_ids, held_keys[k], held_owner[k], known, ji, mw->slot_of, pl));
+        if (!st.ok())
+            break;
         if (pl.own.size() != owned_count[s.rank]) {
             st.keep(set_error(XPBD_E_HIP, "xpbd_multi_world: rank %u is to own %u bodies but finds %zu (inconsistent plans)", s.rank, owned_count[s.rank],
                               pl.own.size()));
             break;
-        }
-        // joints that leave the rank: the other end was published by its holder (or is held here and goes elsewhere)
-        std::vector<HaloPlanner::CrossJoint> cross;
-        if (!mw->joints.empty()) {
-            for (uint32_t g : pl.own)
-                mw->slot_of[g] = 0; // (scratch: the bodies the shard will own)
-            for (uint32_t g : pl.own) {
-                for (uint32_t e = mw->joint_off[g]; e < mw->joint_off[g + 1] && st.ok(); ++e) {
-                    const xpbd_joint &j = mw->joints[mw->joint_adj[e]];
-                    const uint32_t other = j.body_a == g ? j.body_b : j.body_a;
-                    if (mw->slot_of[other] >= 0)
-                        continue;
-                    if (!known.count(other)) {
-                        st.keep(set_error(XPBD_E_HIP, "xpbd_multi_world: body %u (joint %u) is in nobody's rim (inconsistent plans)", other, mw->joint_adj[e]));
-                        break;
-                    }
-                    cross.push_back(HaloPlanner::CrossJoint{g, other});
-                }
-            }
-            for (uint32_t g : pl.own)
-                mw->slot_of[g] = -1;
-        }
-        if (!st.ok())
-            break;
-        HaloPlanner::plan_lists(pl.own, own_keys, foreign, cross, pl.ghosts, pl.boundary, &pl.far);
-        pl.ghost_owner.resize(pl.ghosts.size());
-        pl.ghost_holder.resize(pl.ghosts.size());
-        for (size_t i = 0; i < pl.ghosts.size(); ++i) {
-            const Known &kn = known[pl.ghosts[i]];
-            pl.ghost_owner[i] = kn.owner, pl.ghost_holder[i] = kn.holder;
         }
         exports_of(s, held_owner[k], pl.boundary, pl.exports);
     }
@@ -2466,6 +2499,72 @@ int xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n_
     std::vector<Cut> cuts;
     int axes[3];
     compute_owners(cell_keys, n_global, n_ranks, owner, cuts, axes);
+    return XPBD_OK;
+}
+
+int xpbd_halo_plan_light(const int64_t *keys_at_cut, const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank,
+                         const xpbd_joint *joints, uint32_t n_joints, uint8_t *owner_now, uint32_t *own, uint32_t *n_own, uint32_t *ghosts,
+                         uint32_t *n_ghosts, uint32_t *boundary, uint32_t *n_boundary, uint8_t *far, uint32_t cap)
+{
+    if (!keys_at_cut || !cell_keys || !owner_now || !n_own || !n_ghosts || !n_boundary || n_ranks == 0 || n_ranks > 64 || rank >= n_ranks ||
+        (n_joints && !joints) || (cap && (!own || !ghosts || !boundary)))
+        return set_error(XPBD_E_INVALID, "xpbd_halo_plan_light: bad argument");
+    for (uint32_t j = 0; j < n_joints; ++j)
+        if (joints[j].body_a >= n_global || joints[j].body_b >= n_global)
+            return set_error(XPBD_E_INVALID, "xpbd_halo_plan_light: joint %u names a body out of range", j);
+    // the cuts of the last full plan; who holds what since
+    std::vector<Cut> cuts;
+    int axes[3];
+    std::vector<uint8_t> holder(n_global);
+    compute_owners(keys_at_cut, n_global, n_ranks, holder.data(), cuts, axes);
+    // the joints at every body
+    std::vector<uint32_t> joint_off((size_t)n_global + 1, 0), joint_adj((size_t)2 * n_joints, 0);
+    for (uint32_t j = 0; j < n_joints; ++j)
+        ++joint_off[joints[j].body_a + 1], ++joint_off[joints[j].body_b + 1];
+    for (uint32_t g = 0; g < n_global; ++g)
+        joint_off[g + 1] += joint_off[g];
+    {
+        std::vector<uint32_t> cursor(joint_off.begin(), joint_off.end() - 1);
+        for (uint32_t j = 0; j < n_joints; ++j) {
+            joint_adj[cursor[joints[j].body_a]++] = j;
+            joint_adj[cursor[joints[j].body_b]++] = j;
+        }
+    }
+    const JointIndex ji{joints, joint_off.data(), joint_adj.data(), n_joints != 0};
+    // every rank: the bodies it holds, their owners from the kept cuts, its rim
+    const std::vector<int64_t> cut_layers = cut_layers_of(cuts);
+    std::vector<int32_t> slot_of(n_global, -1);
+    std::vector<std::vector<uint32_t>> held_ids(n_ranks);
+    std::vector<std::vector<int64_t>> held_keys(n_ranks), held_slab(n_ranks);
+    std::vector<std::vector<uint8_t>> held_owner(n_ranks);
+    for (uint32_t g = 0; g < n_global; ++g) {
+        const uint32_t h = holder[g];
+        const int64_t slab = slab_key(cell_keys[g], axes);
+        owner_now[g] = (uint8_t)owner_of(cuts, slab, g);
+        held_ids[h].push_back(g);
+        held_keys[h].push_back(cell_keys[g]);
+        held_slab[h].push_back(slab);
+        held_owner[h].push_back(owner_now[g]);
+    }
+    KnownMap known;
+    for (uint32_t h = 0; h < n_ranks; ++h) {
+        std::vector<RimRow> rows;
+        rim_rows_of(h, held_ids[h], held_keys[h], held_owner[h], held_slab[h], cut_layers, ji, slot_of, rows);
+        for (const RimRow &r : rows)
+            known.emplace(r.id, Known{r.key, r.owner, (uint8_t)h});
+    }
+    ShardPlan pl;
+    if (int rc = light_rank_plan(rank, held_ids[rank], held_keys[rank], held_owner[rank], known, ji, slot_of, pl))
+        return rc;
+    *n_own = (uint32_t)pl.own.size(), *n_ghosts = (uint32_t)pl.ghosts.size(), *n_boundary = (uint32_t)pl.boundary.size();
+    if (pl.own.size() > cap || pl.ghosts.size() > cap || pl.boundary.size() > cap)
+        return set_error(XPBD_E_CAPACITY, "xpbd_halo_plan_light: %zu owned, %zu ghosts, %zu boundary bodies, capacity %u", pl.own.size(), pl.ghosts.size(),
+                         pl.boundary.size(), cap);
+    std::copy(pl.own.begin(), pl.own.end(), own);
+    std::copy(pl.ghosts.begin(), pl.ghosts.end(), ghosts);
+    std::copy(pl.boundary.begin(), pl.boundary.end(), boundary);
+    if (far)
+        std::copy(pl.far.begin(), pl.far.end(), far);
     return XPBD_OK;
 }
 

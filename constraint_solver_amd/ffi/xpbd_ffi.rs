@@ -216,6 +216,9 @@ extern "C" {
     pub fn xpbd_halo_plan_owned(cell_keys: *const i64, owner: *const u8, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint,
                                 n_joints: u32, ghosts: *mut u32, n_ghosts: *mut u32, boundary: *mut u32, n_boundary: *mut u32, far: *mut u8,
                                 cap: u32) -> c_int;
+    pub fn xpbd_halo_plan_light(keys_at_cut: *const i64, cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint,
+                                n_joints: u32, owner_now: *mut u8, own: *mut u32, n_own: *mut u32, ghosts: *mut u32, n_ghosts: *mut u32,
+                                boundary: *mut u32, n_boundary: *mut u32, far: *mut u8, cap: u32) -> c_int;
     pub fn xpbd_halo_plan_far(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, far: *mut u8, cap: u32, n_owned: *mut u32) -> c_int;
     pub fn xpbd_halo_plan(cell_keys: *const i64, n_global: u32, n_ranks: u32, rank: u32, joints: *const XpbdJoint, n_joints: u32,
                           ghosts: *mut u32, n_ghosts: *mut u32, boundary: *mut u32, n_boundary: *mut u32, cap: u32) -> c_int;

@@ -441,6 +441,15 @@ int  xpbd_halo_partition(const int64_t *cell_keys, uint32_t n_global, uint32_t n
 int  xpbd_halo_plan_owned(const int64_t *cell_keys, const uint8_t *owner, uint32_t n_global, uint32_t n_ranks, uint32_t rank,
                           const xpbd_joint *joints, uint32_t n_joints, uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary,
                           uint32_t *n_boundary, uint8_t *far, uint32_t cap);
+/* One rank's LIGHT plan, as the re-plans of xpbd_multi_world compute it: the cuts are those of xpbd_halo_partition for
+ * `keys_at_cut` (where the bodies were when the slabs were cut last; every body is still held by the rank that owned it then),
+ * a body's owner now (owner_now[g], all n_global of them) follows from its present cell key and those cuts, and the rank plans
+ * from the bodies it holds plus the RIMS every holder would publish (bodies within two layers of a cut, bodies that change
+ * owner, ends of joints that leave their holder).  own: what the rank will own (ascending); ghosts / boundary / far as
+ * xpbd_halo_plan_owned, which must give the same lists for (cell_keys, owner_now). */
+int  xpbd_halo_plan_light(const int64_t *keys_at_cut, const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank,
+                          const xpbd_joint *joints, uint32_t n_joints, uint8_t *owner_now, uint32_t *own, uint32_t *n_own,
+                          uint32_t *ghosts, uint32_t *n_ghosts, uint32_t *boundary, uint32_t *n_boundary, uint8_t *far, uint32_t cap);
 /* ... the same with ownership by contiguous index ranges (rank r owns the r-th of n_ranks near-equal ranges). */
 int  xpbd_halo_plan_far(const int64_t *cell_keys, uint32_t n_global, uint32_t n_ranks, uint32_t rank, uint8_t *far, uint32_t cap,
                         uint32_t *n_owned);

@@ -187,3 +187,37 @@ def test_native_plan_with_library_owners_equals_python_plan(world_size):
         ghosts_index_ranges += len(capi.halo_plan(keys, world_size, rank, joints)[0])
     total = sum(len(g) for g in plan.ghosts)
     assert 0 < total < 0.5 * ghosts_index_ranges                   # slabs of space, not index ranges of a shuffled scene
+
+
+@pytest.mark.parametrize("world_size", [2, 3, 5, 8])
+@pytest.mark.parametrize("layout", ["flat", "cloud", "few cells", "tall"])
+@pytest.mark.parametrize("motion", [0.0, 0.3, 2.5, 12.0])
+def test_light_plan_equals_the_full_planner_after_any_motion(world_size, layout, motion):
+    """A LIGHT plan (the re-plans of xpbd_multi_world: the cuts of the last full plan kept, every body still held by its old
+    owner, only the RIMS of the shards known to everybody -- bodies within two layers of a cut, bodies that change owner, ends
+    of joints that leave their holder) must give every rank exactly the lists the full planner computes from the keys and
+    owners of the whole world: what it owns, its ghosts, its boundary bodies, its far flags.  Random worlds (a flat grid
+    world, a 3-D cloud, a world of a handful of cells where cuts split cells, a tall one), random joints between arbitrary
+    bodies, and bodies that have moved since the cut by nothing, a fraction of a cell, a cell, or many cells (several cuts)."""
+    rng = np.random.default_rng(1000 * world_size + int(motion * 10) + len(layout))
+    n, edge = 1500, 2.8
+    extent = {"flat": (120.0, 60.0, 2.0), "cloud": (40.0, 30.0, 20.0), "few cells": (5.0, 4.0, 3.0), "tall": (6.0, 5.0, 200.0)}[layout]
+    before = rng.uniform(0.0, 1.0, (n, 3)) * np.array(extent)
+    after = before + rng.normal(0.0, 1.0, (n, 3)) * motion * edge / 2.0
+    if motion:
+        after[: n // 10] = rng.uniform(0.0, 1.0, (n // 10, 3)) * np.array(extent)        # and a tenth of them anywhere at all
+    k0 = np.array([capi.halo_cell_key(c, edge) for c in before], dtype=np.int64)
+    k1 = np.array([capi.halo_cell_key(c, edge) for c in after], dtype=np.int64)
+    joints = np.zeros(120, dtype=capi.JOINT_DTYPE)
+    a = rng.choice(n, 120, replace=False)
+    b = (a + rng.integers(1, n, 120)) % n
+    joints["body_a"], joints["body_b"] = a, b
+    moved = 0
+    for rank in range(world_size):
+        owner, own, ghosts, boundary, far = capi.halo_plan_light(k0, k1, world_size, rank, joints)
+        if rank == 0:
+            moved = int((owner != capi.halo_partition(k0, world_size)).sum())
+        assert np.array_equal(own, np.nonzero(owner == rank)[0])
+        want_ghosts, want_boundary, want_far = capi.halo_plan_owned(k1, owner, world_size, rank, joints, with_far=True)
+        assert np.array_equal(ghosts, want_ghosts) and np.array_equal(boundary, want_boundary) and np.array_equal(far, want_far)
+    assert moved > 0 or motion == 0.0 or layout == "few cells"
