@@ -140,7 +140,10 @@ __device__ __forceinline__ uint32_t face_contact_group(const PolytopeTables &t, 
                                                        double (*poly0)[3], double (*poly1)[3], double (*ref)[3], M *m,
                                                        uint32_t lane, uint32_t &iface)
 {
-    static_assert(P <= L && P <= 16, "one polygon vertex per lane");
+    // VPL polygon vertices per lane: vertex k of a polygon belongs to lane k % L, turn k / L.  One per lane where the group
+    // is at least as wide as the polygon capacity; the 4-lane groups of box pairs take two turns.
+    constexpr uint32_t VPL = (P + L - 1) / L;
+    static_assert(P <= 16 && VPL * L >= P && VPL * L >= kMaxFaceVerts, "every polygon and face vertex has a lane and a turn");
     const double *rp = t.planes + 4 * (size_t)(dr.face0 + ref_face);
     const Plane ref_plane = fr * Plane{Vec3{rp[0], rp[1], rp[2]}, rp[3]}; // frames.0 * polytopes.0.plane(face), :66
 
@@ -160,54 +163,76 @@ __device__ __forceinline__ uint32_t face_contact_group(const PolytopeTables &t, 
     if (iface == 0xFFFFFFFFu)
         iface = 0;
 
-    // Sutherland-Hodgman with ONE POLYGON VERTEX PER LANE (polygons have <= 16 vertices): every lane
-    // tests its edge (p0 -> p1) against the side plane, a prefix sum of the 0/1/2 points it emits
-    // gives their slots, so the output order is exactly that of the sequential algorithm.
+    // Sutherland-Hodgman with the polygon's vertices spread over the lanes (polygons have <= 16 vertices): every vertex
+    // tests its edge (p0 -> p1) against the side plane, a prefix sum of the 0/1/2 points it emits gives their slots, so
+    // the output order is exactly that of the sequential algorithm.
     const uint32_t *rv = t.face_verts + t.face_start[dr.face0 + ref_face];
     const uint32_t nr = t.face_start[dr.face0 + ref_face + 1] - t.face_start[dr.face0 + ref_face];
     const uint32_t *iv = t.face_verts + t.face_start[di.face0 + iface];
     uint32_t np = t.face_start[di.face0 + iface + 1] - t.face_start[di.face0 + iface];
-    Vec3 inc_vertex{0.0, 0.0, 0.0}, ref_vertex{0.0, 0.0, 0.0};
-    if (lane < np)
-        inc_vertex = ld3(world_i, iv[lane]);
-    if (lane < nr && lane < kMaxFaceVerts)
-        ref_vertex = ld3(world_r, rv[lane]);
+    Vec3 inc_vertex[VPL], ref_vertex[VPL];
+#pragma unroll
+    for (uint32_t v = 0; v < VPL; ++v) {
+        const uint32_t k = v * L + lane;
+        inc_vertex[v] = ref_vertex[v] = Vec3{0.0, 0.0, 0.0};
+        if (k < np)
+            inc_vertex[v] = ld3(world_i, iv[k]);
+        if (k < nr && k < kMaxFaceVerts)
+            ref_vertex[v] = ld3(world_r, rv[k]);
+    }
     __syncthreads();
     // the reference face's vertices by index once, lane-parallel: the clipping loop below then reads LDS only
     // (phase timing: the three dependent global index loads per side plane were ~40 % of the loop)
-    if (lane < np)
-        st3(poly0, lane, inc_vertex);
-    if (lane < nr && lane < kMaxFaceVerts)
-        st3(ref, lane, ref_vertex);
+#pragma unroll
+    for (uint32_t v = 0; v < VPL; ++v) {
+        const uint32_t k = v * L + lane;
+        if (k < np)
+            st3(poly0, k, inc_vertex[v]);
+        if (k < nr && k < kMaxFaceVerts)
+            st3(ref, k, ref_vertex[v]);
+    }
     __syncthreads();
     double(*cur)[3] = poly0, (*nxt)[3] = poly1;
+    const uint64_t below = (1ull << lane) - 1ull;
     for (uint32_t e = 0; e < nr && np > 0; ++e) {
         const Vec3 a = ld3(ref, e), bnext = ld3(ref, (e + 1) % nr);
         const Vec3 c = ld3(ref, (e + 2) % nr);
         Vec3 side = cross(bnext - a, ref_plane.normal);
         if (dot(side, c - a) > 0.0)
             side = -side;
-        Vec3 p0{0.0, 0.0, 0.0}, p1{0.0, 0.0, 0.0};
-        double d0 = 0.0, d1 = 0.0;
-        bool in0 = false, crossing = false;
-        if (lane < np) {
-            p0 = ld3(cur, lane);
-            p1 = ld3(cur, lane + 1 == np ? 0u : lane + 1);
-            d0 = dot(side, p0 - a);
-            d1 = dot(side, p1 - a);
-            in0 = d0 <= 0.0;
-            crossing = in0 != (d1 <= 0.0);
+        Vec3 p0[VPL], p1[VPL];
+        double d0[VPL], d1[VPL];
+        bool in0[VPL], crossing[VPL];
+        uint64_t in_bits[VPL], cross_bits[VPL];
+        // slots of the 0 / 1 / 2 points a vertex emits = points emitted by the vertices before it: two ballots and popcounts
+        // per turn over the group's bits of the wave mask (a shuffle scan would be log2(P) round trips)
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < VPL; ++v) {
+            const uint32_t k = v * L + lane;
+            p0[v] = p1[v] = Vec3{0.0, 0.0, 0.0};
+            d0[v] = d1[v] = 0.0;
+            in0[v] = crossing[v] = false;
+            if (k < np) {
+                p0[v] = ld3(cur, k);
+                p1[v] = ld3(cur, k + 1 == np ? 0u : k + 1);
+                d0[v] = dot(side, p0[v] - a);
+                d1[v] = dot(side, p1[v] - a);
+                in0[v] = d0[v] <= 0.0;
+                crossing[v] = in0[v] != (d1[v] <= 0.0);
+            }
+            in_bits[v] = group_bits<L>(__ballot(in0[v]));
+            cross_bits[v] = group_bits<L>(__ballot(crossing[v]));
         }
-        // slots of the 0 / 1 / 2 points a lane emits = points emitted by the lanes below it: two ballots and popcounts
-        // over the group's bits of the wave mask (a shuffle scan would be log2(P) round trips)
-        const uint64_t in_bits = group_bits<L>(__ballot(in0)), cross_bits = group_bits<L>(__ballot(crossing));
-        const uint64_t below = (1ull << lane) - 1ull;
-        const uint32_t total = (uint32_t)(__popcll(in_bits) + __popcll(cross_bits));
-        uint32_t slot = (uint32_t)(__popcll(in_bits & below) + __popcll(cross_bits & below));
-        if (in0 && slot < P)
-            st3(nxt, slot++, p0);
-        if (crossing && slot < P)
-            st3(nxt, slot, p0 + (p1 - p0) * (d0 / (d0 - d1)));
+#pragma unroll
+        for (uint32_t v = 0; v < VPL; ++v) {
+            uint32_t slot = total + (uint32_t)(__popcll(in_bits[v] & below) + __popcll(cross_bits[v] & below));
+            if (in0[v] && slot < P)
+                st3(nxt, slot++, p0[v]);
+            if (crossing[v] && slot < P)
+                st3(nxt, slot, p0[v] + (p1[v] - p0[v]) * (d0[v] / (d0[v] - d1[v])));
+            total += (uint32_t)(__popcll(in_bits[v]) + __popcll(cross_bits[v]));
+        }
         np = total < P ? total : P;
         double(*const swap)[3] = cur;
         cur = nxt;
@@ -215,20 +240,25 @@ __device__ __forceinline__ uint32_t face_contact_group(const PolytopeTables &t, 
         __syncthreads();
     }
     // every clipped point strictly below the reference plane is a contact, in polygon order
-    Vec3 pt{0.0, 0.0, 0.0};
-    double depth = 0.0;
-    bool keep = false;
-    if (lane < np) {
-        pt = ld3(cur, lane);
-        depth = distance(ref_plane, pt);
-        keep = !(depth >= 0.0);
-    }
-    const uint64_t keep_bits = group_bits<L>(__ballot(keep));
-    const uint32_t kept = (uint32_t)__popcll(keep_bits);
-    const uint32_t at = (uint32_t)__popcll(keep_bits & ((1ull << lane) - 1ull));
-    if (keep && at < kMaxManifoldPoints) {
-        const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
-        set_point(*m, at, pt, on_ref);
+    uint32_t kept = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < VPL; ++v) {
+        const uint32_t k = v * L + lane;
+        Vec3 pt{0.0, 0.0, 0.0};
+        double depth = 0.0;
+        bool keep = false;
+        if (k < np) {
+            pt = ld3(cur, k);
+            depth = distance(ref_plane, pt);
+            keep = !(depth >= 0.0);
+        }
+        const uint64_t keep_bits = group_bits<L>(__ballot(keep));
+        const uint32_t at = kept + (uint32_t)__popcll(keep_bits & below);
+        if (keep && at < kMaxManifoldPoints) {
+            const Vec3 on_ref = pt - depth * ref_plane.normal; // Plane::project, src/geometry.rs:45-47
+            set_point(*m, at, pt, on_ref);
+        }
+        kept += (uint32_t)__popcll(keep_bits);
     }
     if (lane == 0)
         set_plane(*m, ref_plane);

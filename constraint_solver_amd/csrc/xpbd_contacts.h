@@ -90,9 +90,9 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
                                    uint32_t *last_mask, uint32_t *trace_masks, uint32_t trace_row, hipStream_t stream,
                                    const BodySubset &subset = BodySubset());
 // SAT of every neighbour pair on the post-integrate frames
-// (list: NULL = pre-test inside the SAT kernel, else the two-pass form of launch_sat_pairs)
+// (list: NULL = pre-test inside the SAT kernel, else the two-pass form of launch_sat_pairs; dense: many of the pairs touch)
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
-                                    uint32_t n_pairs, SatScratch *list, hipStream_t stream);
+                                    uint32_t n_pairs, SatScratch *list, hipStream_t stream, bool dense = false);
 // Jacobi pair solve + derive: reads the records, writes all 13 dynamic fields to dyn_out (b.dyn itself is fine: nobody
 // reads another body's SoA state here)
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,

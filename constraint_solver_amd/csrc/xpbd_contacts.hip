@@ -1281,9 +1281,9 @@ hipError_t launch_integrate_ground(const BodyArrays &b, const ShapeTable &s, dou
 }
 
 hipError_t launch_sat_contact_pairs(const BodyArrays &b, const PolytopeTables &t, const ContactBuffers &c,
-                                    uint32_t n_pairs, SatScratch *list, hipStream_t stream)
+                                    uint32_t n_pairs, SatScratch *list, hipStream_t stream, bool dense)
 {
-    return launch_sat_contacts(b, t, c.rec, c.pairs, n_pairs, c.manifolds, c.pair_codes, list, stream);
+    return launch_sat_contacts(b, t, c.rec, c.pairs, n_pairs, c.manifolds, c.pair_codes, list, stream, dense);
 }
 
 hipError_t launch_pair_solve_derive(const BodyArrays &b, double *dyn_out, double h, const ContactBuffers &c,

@@ -127,6 +127,7 @@ hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, con
                                hipStream_t stream, bool use_axis_cache = false, const double *gjk_axis_cache = nullptr);
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
                                uint32_t n_pairs, ContactManifold *out, uint8_t *codes, SatScratch *list,
-                               hipStream_t stream); // contact pipeline: sphere pre-test, `list` = two-pass form
+                               hipStream_t stream, bool dense = false); // contact pipeline: sphere pre-test, `list` = two-pass form;
+                                                                        // dense: many of the pairs touch (narrower groups for boxes)
 
 } // namespace xpbd

@@ -36,6 +36,9 @@ constexpr uint32_t kMaxV = XPBD_MAX_SHAPE_VERTS; // 32
 #ifndef XPBD_SAT_BOX_LANES
 #define XPBD_SAT_BOX_LANES 8 // shapes of <= 8 vertices and faces with <= 4 vertices per face: clipped polygons have <= 8 vertices
 #endif
+#ifndef XPBD_SAT_DENSE_BOX_LANES
+#define XPBD_SAT_DENSE_BOX_LANES 4 // ... in dense scenes with at least 65 536 pairs (for_shape_maxima)
+#endif
 #ifndef XPBD_SAT_SMALL_LANES
 #define XPBD_SAT_SMALL_LANES 16 // shapes of <= 8 vertices and faces otherwise
 #endif
@@ -129,8 +132,9 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
                                          uint16_t *__restrict__ axis_cache = nullptr, uint8_t *__restrict__ codes = nullptr, bool cache_edge_axes = false)
 {
     constexpr uint32_t H = L / 2;             // lanes per body in the two-sided stages
-    constexpr uint32_t P = L < 16 ? L : 16;   // polygon capacity of the clipper: one vertex per lane, at most 16 (the
-                                              // launcher uses L = 8 only where no polygon can exceed 8 vertices)
+    constexpr uint32_t P = L < 8 ? 8 : (L < 16 ? L : 16); // polygon capacity of the clipper: one vertex per lane, at most 16 (the
+                                                          // launcher uses L <= 8 only where no polygon can exceed 8 vertices;
+                                                          // 4-lane groups take two turns: xpbd_clip.hpp)
     // ---- group-uniform inputs ---------------------------------------------------------------------
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
@@ -383,7 +387,7 @@ __device__ __forceinline__ bool tight_spheres_overlap(const BodyArrays &b, const
 template <uint32_t L, uint32_t V>
 struct SatLds {
     static constexpr uint32_t PW = 64 / L;            // pairs per wave
-    static constexpr uint32_t P = L < 16 ? L : 16;    // one polygon vertex per lane, at most 16
+    static constexpr uint32_t P = L < 8 ? 8 : (L < 16 ? L : 16); // polygon capacity (sat_pair)
     static_assert(V == 8 || V == 16 || V == kMaxV, "vertex capacity per body");
     using Record = PairLds<V, P, PW>;
     static_assert(sizeof(Record) % 8 == 0, "pair records must stay 8-byte aligned");
@@ -694,11 +698,17 @@ namespace {
 // most 8, one per lane) and the launch is large; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
 // 16-vertex records; anything larger gets a whole wave.
 template <class Launch>
-void for_shape_maxima(uint32_t max_verts, uint32_t max_faces, uint32_t max_face_verts, uint32_t n_pairs, Launch launch)
+void for_shape_maxima(uint32_t max_verts, uint32_t max_faces, uint32_t max_face_verts, uint32_t n_pairs, bool dense, Launch launch)
 {
     // 8 lanes per pair halve the instructions per pair of the clipping half of the SAT (208 -> 148 us on 245 760 box
-    // pairs) but lengthen the chain of a wave: only when there are enough pairs to fill the GPU with 8-pair waves
-    if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && n_pairs >= kWidePairCount)
+    // pairs) but lengthen the chain of a wave: only when there are enough pairs to fill the GPU with 8-pair waves.
+    // 4 lanes per pair (round 3; the clipper takes two polygon vertices per lane then) halve again what a group computes
+    // redundantly on all its lanes -- frames, feature choice, side planes -- and fill the rounds of the face and edge
+    // loops: another 13 % off the SAT of a boxes pile and of box stacks; only in DENSE scenes (the caller's judgement: many
+    // of the pairs touch) with twice as many pairs, where the longer chain of a 16-pair wave is hidden.
+    if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && dense && n_pairs >= 2 * kWidePairCount)
+        launch(std::integral_constant<uint32_t, XPBD_SAT_DENSE_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
+    else if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && n_pairs >= kWidePairCount)
         launch(std::integral_constant<uint32_t, XPBD_SAT_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
     else if (max_verts <= 8 && max_faces <= 8)
         launch(std::integral_constant<uint32_t, XPBD_SAT_SMALL_LANES>{}, std::integral_constant<uint32_t, 8>{});
@@ -709,9 +719,9 @@ void for_shape_maxima(uint32_t max_verts, uint32_t max_faces, uint32_t max_face_
 }
 
 template <class Launch>
-void for_shape_class(const PolytopeTables &t, uint32_t n_pairs, Launch launch)
+void for_shape_class(const PolytopeTables &t, uint32_t n_pairs, bool dense, Launch launch)
 {
-    for_shape_maxima(t.max_verts, t.max_faces, t.max_face_verts, n_pairs, launch);
+    for_shape_maxima(t.max_verts, t.max_faces, t.max_face_verts, n_pairs, dense, launch);
 }
 } // namespace
 
@@ -719,7 +729,7 @@ hipError_t launch_sat_pairs(const BodyArrays &b, const PolytopeTables &t, const 
                             uint32_t n_pairs, Manifold *out, hipStream_t stream)
 {
     if (n_pairs)
-        for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
+        for_shape_class(t, n_pairs, false, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_pairs<L, V, false, Manifold>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t,
                                frames, pairs, n_pairs, out, nullptr);
@@ -748,7 +758,7 @@ hipError_t launch_pair_pretest(const BodyArrays &b, const PolytopeTables &t, con
 }
 
 hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, const double *frames, const uint32_t *pairs,
-                               uint32_t n_pairs, ContactManifold *out, uint8_t *codes, SatScratch *list, hipStream_t stream)
+                               uint32_t n_pairs, ContactManifold *out, uint8_t *codes, SatScratch *list, hipStream_t stream, bool dense)
 {
     if (n_pairs == 0)
         return hipSuccess;
@@ -762,7 +772,7 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         ++list->calls;
         hipLaunchKernelGGL(k_pair_pretest<true>, dim3((n_pairs + kPretestBlock - 1) / kPretestBlock), dim3(kPretestBlock), 0, stream, b, t,
                            frames, pairs, n_pairs, codes, count, list->survivors, list->axis_cache, nullptr);
-        for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, [&](auto lanes, auto verts) {
+        for_shape_maxima(8, 8, t.small_max_face_verts, n_pairs, dense, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs, count,
                                next, list->survivors, 0u, out, list->axis_cache, codes, list->cache_edge_axes);
@@ -773,14 +783,14 @@ hipError_t launch_sat_contacts(const BodyArrays &b, const PolytopeTables &t, con
         else
             hipLaunchKernelGGL((k_sat_survivors<32, kMaxV>), dim3((n_pairs + 1) / 2), dim3(64), 0, stream, b, t, frames, pairs, count + 1, next,
                                list->survivors, n_pairs, out, list->axis_cache, codes, list->cache_edge_axes);
-        for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
+        for_shape_class(t, n_pairs, dense, [&](auto lanes, auto verts) {
             constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
             hipLaunchKernelGGL((k_sat_survivors<L, V>), dim3((n_pairs + 64 / L - 1) / (64 / L)), dim3(64), 0, stream, b, t, frames, pairs,
                                count + 2, next, list->survivors + n_pairs, 0u, out, list->axis_cache, codes, list->cache_edge_axes);
         });
         return hipGetLastError();
     }
-    for_shape_class(t, n_pairs, [&](auto lanes, auto verts) {
+    for_shape_class(t, n_pairs, dense, [&](auto lanes, auto verts) {
         constexpr uint32_t L = decltype(lanes)::value, V = decltype(verts)::value;
         const dim3 grid((n_pairs + 64 / L - 1) / (64 / L));
         if (list) { // pre-test pass, then the SAT over the survivors

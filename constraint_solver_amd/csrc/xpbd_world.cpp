@@ -363,9 +363,11 @@ int build_neighbours_collect(xpbd_world *w)
             w->sat_two_pass = touching * 5 < examined * 4;
         if (w->sat_schedule == XPBD_SAT_SCHEDULE_AUTO && w->two_classes)
             w->sat_two_pass = true; // small and large shapes: the two-pass form sorts the pairs by class (xpbd_pairs.h)
-        // Separating EDGE axes in the axis cache (SatScratch)?  Trying one costs the pre-test a whole edge query for every
-        // wave that holds such a pair; it pays where many pairs are close (piles: 35-40 % of the pairs touch, +4 % / +9 %),
-        // not where a few are (chains of spaced boxes: 5 % touch, -4 %).  Same bits either way.
+        // A DENSE scene (>= 15 % of the pairs examined in the last frame touched)?  Then (a) separating EDGE axes go into the
+        // axis cache (SatScratch): trying one costs the pre-test a whole edge query for every wave that holds such a pair; it
+        // pays where many pairs are close (piles: 35-40 % of the pairs touch, +4 % / +9 %), not where a few are (chains of
+        // spaced boxes: 5 % touch, -4 %); and (b) box pairs run in groups of four lanes instead of eight (for_shape_maxima:
+        // piles and stacks +7 %, the chains -3 %).  Same bits either way.
         if (examined)
             w->sat_scratch.cache_edge_axes = touching * 100 >= examined * 15;
         w->stats_touching_seen = stats_now[0];
@@ -419,7 +421,7 @@ int narrowphase_contacts(xpbd_world *w, const xpbd::BodyArrays &b, const xpbd::C
                                                 w->gjk_scratch, true, &w->sat_scratch, w->stream));
     } else {
         XPBD_HIP_TRY(xpbd::launch_sat_contact_pairs(b, w->tables(), c, w->n_pairs, w->sat_two_pass ? &w->sat_scratch : nullptr,
-                                                    w->stream));
+                                                    w->stream, w->sat_scratch.cache_edge_axes /* = a dense scene, see below */));
     }
     w->stats_pair_substeps += w->n_pairs;
     return XPBD_OK;
