@@ -19,6 +19,7 @@
 // Kernels: k_sat_pairs (every listed pair; optionally with the contact pipeline's tight-sphere pre-test),
 // k_pair_pretest + k_sat_survivors (the pre-test as a pass of its own, the SAT over the survivors only).
 #include <cfloat>
+#include <cstdlib>
 
 #include <type_traits>
 
@@ -697,18 +698,27 @@ namespace {
 // pairs per wave with 8-vertex records -- eight when no face has more than 4 vertices (a clipped polygon then has at
 // most 8, one per lane) and the launch is large; up to 16 vertices (icosahedra) XPBD_SAT_MID_LANES lanes with
 // 16-vertex records; anything larger gets a whole wave.
+// (XPBD_SAT_WIDE_PAIRS in the environment overrides the pair count from which the narrow groups are taken -- the tests set it
+// to 1 so that small random scenes run through the 8- and 4-lane classes too; read at every launch, so a test can set it)
+uint32_t wide_pair_count()
+{
+    const char *e = std::getenv("XPBD_SAT_WIDE_PAIRS");
+    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : kWidePairCount;
+}
+
 template <class Launch>
 void for_shape_maxima(uint32_t max_verts, uint32_t max_faces, uint32_t max_face_verts, uint32_t n_pairs, bool dense, Launch launch)
 {
+    const uint32_t wide = wide_pair_count();
     // 8 lanes per pair halve the instructions per pair of the clipping half of the SAT (208 -> 148 us on 245 760 box
     // pairs) but lengthen the chain of a wave: only when there are enough pairs to fill the GPU with 8-pair waves.
     // 4 lanes per pair (round 3; the clipper takes two polygon vertices per lane then) halve again what a group computes
     // redundantly on all its lanes -- frames, feature choice, side planes -- and fill the rounds of the face and edge
     // loops: another 13 % off the SAT of a boxes pile and of box stacks; only in DENSE scenes (the caller's judgement: many
     // of the pairs touch) with twice as many pairs, where the longer chain of a 16-pair wave is hidden.
-    if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && dense && n_pairs >= 2 * kWidePairCount)
+    if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && dense && n_pairs >= 2 * (size_t)wide)
         launch(std::integral_constant<uint32_t, XPBD_SAT_DENSE_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
-    else if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && n_pairs >= kWidePairCount)
+    else if (max_verts <= 8 && max_faces <= 8 && max_face_verts <= 4 && n_pairs >= wide)
         launch(std::integral_constant<uint32_t, XPBD_SAT_BOX_LANES>{}, std::integral_constant<uint32_t, 8>{});
     else if (max_verts <= 8 && max_faces <= 8)
         launch(std::integral_constant<uint32_t, XPBD_SAT_SMALL_LANES>{}, std::integral_constant<uint32_t, 8>{});

@@ -28,3 +28,17 @@ def test_fuzz_contact_pipeline_against_its_oracle():
         assert ok, "case %d: %s" % (case, what)
         touching += "touching 0 " not in what
     assert touching >= 8                             # ... and body-body contacts
+
+
+def test_fuzz_contact_pipeline_with_narrow_groups(monkeypatch):
+    """The same kind of cases with XPBD_SAT_WIDE_PAIRS=1: every SAT launch takes the narrow groups that only large launches get
+    otherwise -- eight lanes per box pair, and four in dense scenes (16 pairs per wave, the clipper two polygon vertices per
+    lane): all group widths must give the bits of the oracle."""
+    monkeypatch.setenv("XPBD_SAT_WIDE_PAIRS", "1")
+    rng = np.random.default_rng(20260405)
+    touching = 0
+    for case in range(12):
+        ok, what = contacts_case(rng, max_bodies=1500)
+        assert ok, "case %d: %s" % (case, what)
+        touching += "touching 0 " not in what
+    assert touching >= 9
