@@ -133,9 +133,9 @@ __device__ __forceinline__ void sat_pair(Lds &s, const BodyArrays &b, const Poly
                                          uint16_t *__restrict__ axis_cache = nullptr, uint8_t *__restrict__ codes = nullptr, bool cache_edge_axes = false)
 {
     constexpr uint32_t H = L / 2;             // lanes per body in the two-sided stages
-    constexpr uint32_t P = L < 8 ? 8 : (L < 16 ? L : 16); // polygon capacity of the clipper: one vertex per lane, at most 16 (the
-                                                          // launcher uses L <= 8 only where no polygon can exceed 8 vertices;
-                                                          // 4-lane groups take two turns: xpbd_clip.hpp)
+    constexpr uint32_t P = (Lds::kVerts <= 8 && L <= 8) ? 8 : 16; // polygon capacity of the clipper: 8 in the box classes (the launcher
+                                                                  // takes them only where no polygon can exceed 8 vertices), else 16;
+                                                                  // groups narrower than that take several turns (xpbd_clip.hpp)
     // ---- group-uniform inputs ---------------------------------------------------------------------
     const uint32_t ia = pairs[2 * (size_t)p], ib = pairs[2 * (size_t)p + 1];
     const Frame fa = load_record_p1(frames, ia), fb = load_record_p1(frames, ib);
@@ -388,7 +388,7 @@ __device__ __forceinline__ bool tight_spheres_overlap(const BodyArrays &b, const
 template <uint32_t L, uint32_t V>
 struct SatLds {
     static constexpr uint32_t PW = 64 / L;            // pairs per wave
-    static constexpr uint32_t P = L < 8 ? 8 : (L < 16 ? L : 16); // polygon capacity (sat_pair)
+    static constexpr uint32_t P = (V <= 8 && L <= 8) ? 8 : 16;   // polygon capacity (sat_pair)
     static_assert(V == 8 || V == 16 || V == kMaxV, "vertex capacity per body");
     using Record = PairLds<V, P, PW>;
     static_assert(sizeof(Record) % 8 == 0, "pair records must stay 8-byte aligned");
